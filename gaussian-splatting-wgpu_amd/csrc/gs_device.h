@@ -1,0 +1,132 @@
+// gs_device.h -- shared device-side definitions for the gfx950 kernels.
+//
+// Canonical float semantics (DESIGN.md "Bit-exactness"): the kernels that feed integer outputs
+// (rects, tile counts, sort keys) evaluate every WGSL expression as written, left to right, one
+// IEEE binary32 rounding per operation.  The whole library is compiled with -ffp-contract=off,
+// so a*b+c is two roundings unless it is written as __builtin_fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GS_WAVE 64
+
+// ---- frame constants, passed by value to every kernel -------------------------------------------
+struct GsFrame {
+    uint32_t n;          // gaussians
+    uint32_t width, height, tile_size;
+    uint32_t ntx, nty;   // ceil(f32(W)/f32(ts)) (process_gaussians.wgsl:79)
+    uint32_t col0, col1; // tile-column slab [col0,col1)
+    uint32_t px0, slab_w;// first pixel column and pixel width of the slab
+    uint32_t capacity;   // entries the (key,value) arrays can hold
+    uint32_t full;       // col0==0 && col1==ntx
+};
+
+// ---- device-resident control block (zeroed by one memset per frame) -----------------------------
+// Every word another workgroup polls lives here or in the status arrays that follow it.
+struct GsControl {
+    uint32_t scan_ticket;     // dynamic block ids for the tile-count scan
+    uint32_t sort_ticket[4];  // dynamic tile ids, one per radix pass
+    uint32_t fault;           // set when a bounded spin gives up
+    uint32_t overflow;        // set when I exceeds capacity
+    uint32_t num_intersections; // I (written by the scan's last block)
+    uint32_t num_visible;
+    uint32_t pad0;
+    unsigned long long num_processed; // blend: staged list entries
+    uint32_t hist[4][256];    // digit histograms -> exclusive digit bases
+};
+
+struct GsScene {
+    const float* px; const float* py; const float* pz;
+    const float* sx; const float* sy; const float* sz;
+    const float4* rot;
+    const float* opac;
+    const float4* sh; // [12][n]
+};
+
+struct GsUniforms { // 160 B, renderer.ts:15-24
+    float view[16];
+    float proj[16];
+    float cam[3];
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+};
+
+// ---- canonical scalar helpers (same definitions as the oracle, written independently) -----------
+__device__ __forceinline__ float wg_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float wg_min(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ int wg_maxi(int a, int b) { return (a < b) ? b : a; }
+__device__ __forceinline__ int wg_mini(int a, int b) { return (b < a) ? b : a; }
+
+// f32 -> i32: truncate, saturate, NaN -> 0
+__device__ __forceinline__ int f2i_sat(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)x;
+}
+__device__ __forceinline__ uint32_t f2u_sat(float x) {
+    if (x != x) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    if (x <= 0.0f) return 0u;
+    return (uint32_t)x;
+}
+
+// Canonical exp: Cody-Waite reduction by ln2 (hi/lo), degree-5 polynomial, two-step power-of-two
+// scaling.  Only IEEE fma/mul/add/rint, so it is bit-identical to the CPU oracle's exp.
+__device__ __forceinline__ float gs_exp(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -103.97208404541015625f) return 0.0f;
+    const float nf = __builtin_rintf(x * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(-nf, 0.693145751953125f, x);
+    r = __builtin_fmaf(-nf, 1.42860677465796470642e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float z = r * r;
+    float y = __builtin_fmaf(p, z, r);
+    y = y + 1.0f;
+    const int n = (int)nf;
+    const int a = n >> 1;
+    const int b = n - a;
+    const float sa = __uint_as_float((uint32_t)(a + 127) << 23);
+    const float sb = __uint_as_float((uint32_t)(b + 127) << 23);
+    return (y * sa) * sb;
+}
+
+// ---- wave64 helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if ((int)lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---- inter-workgroup words (cdna_hip_programming.md Guideline 16, form R2: the data is the flag) --
+// A status word is one naturally aligned 4- or 8-byte granule written by ONE relaxed agent-scope
+// atomic store (sc1, bypasses L1/keeps no stale copy) and polled with relaxed agent-scope loads.
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define GS_SPIN_LIMIT (1u << 22) // bounded spins: give up, raise GsControl::fault, never hang the GPU

@@ -1,0 +1,508 @@
+// gs_runtime.hip -- context, device arena, frame sequencing and the C ABI (include/gsplat/gs_abi.h).
+//
+// Replaces the frame orchestration of Renderer (reference src/renderer.ts:96-347 setup/teardown,
+// :349-593 animate) and the host halves of ExclusiveScanner (src/exclusive_scan.ts:208-325) and
+// GPUSorter (src/radix_sort/sort.ts:249-350).  Where the reference blocks on the queue 8 times per
+// frame, reads I back to the CPU, allocates six sort buffers and clears three buffers per frame,
+// this runtime enqueues one frame as ~10 kernels + 1 small memset on one HIP stream with no host
+// synchronisation: I stays in device memory, grids are persistent (ticket loops), every buffer is
+// allocated once (capacity-based) and grown geometrically only when a frame overflows.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/gsplat/gs_abi.h"
+#include "gs_kernels.h"
+
+#define GS_EXPORT extern "C" __attribute__((visibility("default")))
+
+static thread_local char g_err[512] = "";
+static int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP, "%s: %s", #expr,      \
+                        hipGetErrorString(e_));                                                             \
+    } while (0)
+
+struct gs_ctx {
+    gs_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    GsFrame frame{};
+    uint32_t T = 0, passes = 0, key_bits = 0;
+    uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
+    uint32_t blend_threads = 0;
+    // scene planes
+    void* scene_mem = nullptr;
+    GsScene scene{};
+    uint32_t n = 0;
+    // per-gaussian frame buffers
+    uint32_t* counts = nullptr;
+    uint32_t* offsets = nullptr;
+    void* gdata = nullptr;
+    // (key,value) arrays
+    uint64_t capacity = 0;
+    uint32_t *keysA = nullptr, *valsA = nullptr, *keysB = nullptr, *valsB = nullptr;
+    uint32_t *keysU = nullptr, *valsU = nullptr; // debug copies of the unsorted arrays
+    uint32_t *keysS = nullptr, *valsS = nullptr; // where the sorted result of the last frame lives
+    // control block + look-back status words (one allocation, one memset per frame)
+    void* ctl_mem = nullptr;
+    size_t ctl_bytes = 0;
+    GsControl* ctl = nullptr;
+    unsigned long long* scan_status = nullptr;
+    uint32_t* sort_status = nullptr;
+    GsControl* h_ctl = nullptr; // pinned
+    // outputs
+    uint32_t* ranges = nullptr;
+    uint32_t* rgba8 = nullptr;
+    float* rgbf = nullptr;
+    uint32_t* d_pxb = nullptr; // assemble: pixel boundaries
+    hipEvent_t ev[GS_STAGE_COUNT + 1] = {};
+    bool have_events = false;
+    // frame state
+    bool have_frame = false, pending = false, last_debug = false;
+    void* last_ext = nullptr;
+    GsUniforms last_u{};
+    uint64_t frames = 0;
+};
+
+static uint32_t tiles_f32(uint32_t extent, uint32_t ts) { // ceil(f32(extent)/f32(ts)), process_gaussians.wgsl:79
+    return (uint32_t)std::ceil((float)extent / (float)ts);
+}
+static uint32_t bits_for(uint64_t v) {
+    uint32_t b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b ? b : 1;
+}
+
+GS_EXPORT const char* gs_last_error(void) { return g_err; }
+GS_EXPORT int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
+
+static void free_kv(gs_ctx* c) {
+    hipFree(c->keysA); hipFree(c->valsA); hipFree(c->keysB); hipFree(c->valsB); hipFree(c->keysU); hipFree(c->valsU);
+    hipFree(c->ctl_mem);
+    c->keysA = c->valsA = c->keysB = c->valsB = c->keysU = c->valsU = nullptr;
+    c->ctl_mem = nullptr;
+}
+
+// (key,value) arrays + the control/status block sized for `capacity` entries.
+static int32_t alloc_kv(gs_ctx* c, uint64_t capacity) {
+    if (capacity >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "capacity %llu exceeds 2^30 intersections", (unsigned long long)capacity);
+    free_kv(c);
+    capacity = std::max<uint64_t>(capacity, 4096);
+    const size_t kb = (size_t)capacity * 4;
+    HIP_TRY(hipMalloc((void**)&c->keysA, kb));
+    HIP_TRY(hipMalloc((void**)&c->valsA, kb));
+    HIP_TRY(hipMalloc((void**)&c->keysB, kb));
+    HIP_TRY(hipMalloc((void**)&c->valsB, kb));
+    const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
+    const size_t scan_sz = (((size_t)gs_scan_blocks(c->n ? c->n : 1) + 1) * 8 + 255) & ~(size_t)255;
+    const size_t sort_sz = (size_t)c->passes * gs_sort_tiles(capacity) * 256 * 4;
+    c->ctl_bytes = ctl_sz + scan_sz + sort_sz;
+    HIP_TRY(hipMalloc(&c->ctl_mem, c->ctl_bytes));
+    c->ctl = (GsControl*)c->ctl_mem;
+    c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz);
+    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + scan_sz);
+    c->capacity = capacity;
+    c->frame.capacity = (uint32_t)capacity;
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
+    if (!cfg || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: null argument");
+    if (cfg->struct_size != sizeof(gs_config)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: struct_size %u != %zu", cfg->struct_size, sizeof(gs_config));
+    if (cfg->width == 0 || cfg->height == 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: empty canvas");
+    if (cfg->tile_size != 8 && cfg->tile_size != 16 && cfg->tile_size != 32)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: tile_size must be 8, 16 or 32 (got %u)", cfg->tile_size);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GS_ERR_NO_DEVICE, "gs_create: no HIP device");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: device %d of %d", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    gs_ctx* c = new (std::nothrow) gs_ctx();
+    if (!c) return fail(GS_ERR_OUT_OF_MEMORY, "gs_create: host allocation failed");
+    c->cfg = *cfg;
+    GsFrame& f = c->frame;
+    f.width = cfg->width; f.height = cfg->height; f.tile_size = cfg->tile_size;
+    f.ntx = tiles_f32(cfg->width, cfg->tile_size);
+    f.nty = tiles_f32(cfg->height, cfg->tile_size);
+    if (f.ntx >= 32768 || f.nty >= 65536) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: canvas too large"); }
+    f.col0 = cfg->col_begin;
+    f.col1 = cfg->col_end;
+    if (f.col0 == 0 && f.col1 == 0) f.col1 = f.ntx;
+    if (f.col1 > f.ntx || f.col0 >= f.col1) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: bad tile-column slab [%u,%u) of %u", f.col0, f.col1, f.ntx); }
+    f.full = (f.col0 == 0 && f.col1 == f.ntx) ? 1u : 0u;
+    f.px0 = f.col0 * f.tile_size;
+    f.slab_w = std::min(f.width, f.col1 * f.tile_size) - f.px0;
+    c->T = f.ntx * f.nty;
+    // largest key a rect can produce: tile (nty*ntx + ntx) (rows/cols one past the grid), bucket 999
+    const uint64_t max_key = ((uint64_t)f.nty * f.ntx + f.ntx) * 1000ull + 999ull;
+    if (max_key > 0xFFFFFFFFull) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: tile ids overflow the 32-bit key (write_tile_ids.wgsl:29)"); }
+    c->key_bits = bits_for(max_key);
+    c->passes = (c->key_bits + 7) / 8;
+
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    c->grid_persist = (uint32_t)prop.multiProcessorCount * 4;
+    if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+
+    HIP_TRY(hipMalloc((void**)&c->ranges, (size_t)c->T * 4));
+    HIP_TRY(hipMemset(c->ranges, 0, (size_t)c->T * 4));
+    const size_t px = (size_t)f.slab_w * f.height;
+    HIP_TRY(hipMalloc((void**)&c->rgba8, px * 4));
+    HIP_TRY(hipMemset(c->rgba8, 0, px * 4));
+    if (cfg->flags & GS_FLAG_F32_TAP) HIP_TRY(hipMalloc((void**)&c->rgbf, px * 12));
+    HIP_TRY(hipHostMalloc((void**)&c->h_ctl, sizeof(GsControl), hipHostMallocDefault));
+    memset(c->h_ctl, 0, sizeof(GsControl));
+    HIP_TRY(hipMalloc((void**)&c->d_pxb, 65 * 4));
+    if (cfg->flags & GS_FLAG_TIMING) {
+        for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+        c->have_events = true;
+    }
+    *out = c;
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
+    if (!c) return GS_OK;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_kv(c);
+    hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
+    hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb);
+    if (c->h_ctl) hipHostFree(c->h_ctl);
+    if (c->have_events) for (auto& e : c->ev) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return GS_OK;
+}
+
+static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
+    hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
+    c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
+    c->n = (uint32_t)n;
+    c->frame.n = (uint32_t)n;
+    c->have_frame = false;
+    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane 256-byte aligned
+    const size_t bytes = np * (6 * 4 + 4 + 16 + 12 * 16);
+    HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
+    char* p = (char*)c->scene_mem;
+    GsScene& s = c->scene;
+    s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
+    s.sx = (float*)p; p += np * 4; s.sy = (float*)p; p += np * 4; s.sz = (float*)p; p += np * 4;
+    s.opac = (float*)p; p += np * 4;
+    s.rot = (float4*)p; p += np * 16;
+    s.sh = (float4*)p;
+    HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
+    HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
+    // NOTE: the SH planes are indexed [plane][n] with stride n (not np) by the kernels
+    if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
+    HIP_TRY(hipGetLastError());
+    uint64_t cap = c->cfg.max_intersections ? c->cfg.max_intersections : std::max<uint64_t>(4 * n, 1u << 22);
+    cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
+    int32_t rc = alloc_kv(c, cap);
+    if (rc != GS_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_upload_splats_device(gs_ctx* c, const void* d_aos, uint64_t n) {
+    if (!c || (!d_aos && n)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats_device: null argument");
+    if (n >= (1ull << 31)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats: too many gaussians");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return upload_common(c, d_aos, n);
+}
+
+GS_EXPORT int32_t gs_upload_splats(gs_ctx* c, const void* aos, uint64_t n) {
+    if (!c || (!aos && n)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats: null argument");
+    if (n >= (1ull << 31)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats: too many gaussians");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    void* d = nullptr;
+    const size_t bytes = (size_t)n * GS_SPLAT_RECORD_BYTES;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(bytes, 256)));
+    if (bytes) {
+        hipError_t e = hipMemcpy(d, aos, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(d); return fail(GS_ERR_HIP, "upload memcpy: %s", hipGetErrorString(e)); }
+    }
+    int32_t rc = upload_common(c, d, n);
+    hipFree(d);
+    return rc;
+}
+
+static inline void mark(gs_ctx* c, int i) {
+    if (c->have_events) hipEventRecord(c->ev[i], c->stream);
+}
+
+static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8) {
+    const GsFrame& f = c->frame;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
+    if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
+    mark(c, 0);
+    gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, c->ctl, st);
+    mark(c, 1);
+    gs_launch_scan(c->counts, c->offsets, c->n, c->scan_status, c->ctl, nullptr, st);
+    mark(c, 2);
+    gs_launch_emit(c->gdata, c->counts, c->offsets, f, c->keysA, c->valsA, c->ctl, st);
+    if (debug) {
+        if (!c->keysU) {
+            HIP_TRY(hipMalloc((void**)&c->keysU, (size_t)c->capacity * 4));
+            HIP_TRY(hipMalloc((void**)&c->valsU, (size_t)c->capacity * 4));
+        }
+        HIP_TRY(hipMemcpyAsync(c->keysU, c->keysA, (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->valsU, c->valsA, (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, st));
+    }
+    mark(c, 3);
+    gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, &c->ctl->num_intersections, (uint32_t)c->capacity, c->passes,
+                   c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
+    mark(c, 4);
+    gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist, st);
+    mark(c, 5);
+    uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
+    if (gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
+                        c->blend_threads, st) != 0)
+        return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
+    mark(c, 6);
+    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipGetLastError());
+    c->pending = true;
+    c->have_frame = true;
+    c->last_debug = debug;
+    c->last_ext = ext_rgba8;
+    c->last_u = u;
+    c->frames++;
+    return GS_OK;
+}
+
+static int32_t render_common(gs_ctx* c, const void* uniforms, bool debug, void* ext) {
+    if (!c || !uniforms) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render: null argument");
+    if (!c->scene_mem) return fail(GS_ERR_NO_SCENE, "gs_render: no splats uploaded");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    GsUniforms u;
+    static_assert(sizeof(GsUniforms) == GS_UNIFORM_BYTES, "uniform block must be 160 bytes");
+    memcpy(&u, uniforms, sizeof(u));
+    return enqueue_frame(c, u, debug, ext);
+}
+GS_EXPORT int32_t gs_render(gs_ctx* c, const void* uniforms) { return render_common(c, uniforms, false, nullptr); }
+GS_EXPORT int32_t gs_render_debug(gs_ctx* c, const void* uniforms) { return render_common(c, uniforms, true, nullptr); }
+GS_EXPORT int32_t gs_render_to(gs_ctx* c, const void* uniforms, void* d_rgba8) {
+    if (!d_rgba8) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render_to: null output");
+    return render_common(c, uniforms, false, d_rgba8);
+}
+
+GS_EXPORT int32_t gs_wait(gs_ctx* c) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_wait: null ctx");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->pending = false;
+        if (!c->have_frame) return GS_OK;
+        if (c->h_ctl->fault) return fail(GS_ERR_DEVICE_FAULT, "a look-back spin exceeded its bound (fault word set)");
+        const uint64_t I = c->h_ctl->num_intersections;
+        if (I <= c->capacity && !c->h_ctl->overflow) return GS_OK;
+        // the frame overflowed the (key,value) capacity: grow geometrically and render it again
+        uint64_t want = std::max<uint64_t>(I + I / 4, c->capacity * 2);
+        if (want >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "%llu intersections exceed the 2^30 limit", (unsigned long long)I);
+        hipFree(c->keysU); hipFree(c->valsU); c->keysU = c->valsU = nullptr;
+        int32_t rc = alloc_kv(c, want);
+        if (rc != GS_OK) return rc;
+        c->frames--;
+        rc = enqueue_frame(c, c->last_u, c->last_debug, c->last_ext);
+        if (rc != GS_OK) return rc;
+    }
+    return fail(GS_ERR_CAPACITY, "capacity did not converge");
+}
+
+GS_EXPORT int32_t gs_slab_width(gs_ctx* c, uint32_t* px_begin, uint32_t* px_width) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_slab_width: null ctx");
+    if (px_begin) *px_begin = c->frame.px0;
+    if (px_width) *px_width = c->frame.slab_w;
+    return GS_OK;
+}
+
+static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
+    const uint64_t I = std::min<uint64_t>(c->h_ctl->num_intersections, c->capacity);
+    const uint64_t px = (uint64_t)c->frame.slab_w * c->frame.height;
+    switch (which) {
+    case GS_BUF_TILE_COUNTS: *ptr = c->counts; *bytes = (uint64_t)c->n * 4; return GS_OK;
+    case GS_BUF_TILE_OFFSETS: *ptr = c->offsets; *bytes = (uint64_t)c->n * 4; return GS_OK;
+    case GS_BUF_GAUSSIAN_DATA: *ptr = c->gdata; *bytes = (uint64_t)c->n * 64; return GS_OK;
+    case GS_BUF_KEYS_UNSORTED:
+    case GS_BUF_VALUES_UNSORTED:
+        if (!c->last_debug || !c->keysU) return fail(GS_ERR_NO_FRAME, "unsorted taps need gs_render_debug");
+        *ptr = which == GS_BUF_KEYS_UNSORTED ? c->keysU : c->valsU; *bytes = I * 4; return GS_OK;
+    case GS_BUF_KEYS: *ptr = c->keysS; *bytes = I * 4; return GS_OK;
+    case GS_BUF_VALUES: *ptr = c->valsS; *bytes = I * 4; return GS_OK;
+    case GS_BUF_RANGES: *ptr = c->ranges; *bytes = (uint64_t)c->T * 4; return GS_OK;
+    case GS_BUF_RGBA8: *ptr = c->last_ext ? c->last_ext : (void*)c->rgba8; *bytes = px * 4; return GS_OK;
+    case GS_BUF_RGB_F32:
+        if (!c->rgbf) return fail(GS_ERR_INVALID_ARGUMENT, "GS_BUF_RGB_F32 needs GS_FLAG_F32_TAP");
+        *ptr = c->rgbf; *bytes = px * 12; return GS_OK;
+    default: return fail(GS_ERR_INVALID_ARGUMENT, "unknown buffer id %d", which);
+    }
+}
+
+GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t size, uint64_t* written) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: null ctx");
+    if (!c->have_frame) return fail(GS_ERR_NO_FRAME, "gs_read_buffer: no frame rendered");
+    if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    void* p = nullptr;
+    uint64_t bytes = 0;
+    int32_t rc = tap(c, which, &p, &bytes);
+    if (rc != GS_OK) return rc;
+    if (written) *written = bytes;
+    if (!dst) return GS_OK;
+    if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
+    if (bytes) HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_read_rgba8(gs_ctx* c, void* dst, uint64_t size) {
+    if (!dst) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_rgba8: null destination");
+    return gs_read_buffer(c, GS_BUF_RGBA8, dst, size, nullptr);
+}
+
+GS_EXPORT int32_t gs_device_ptr(gs_ctx* c, int32_t which, void** d_ptr) {
+    if (!c || !d_ptr) return fail(GS_ERR_INVALID_ARGUMENT, "gs_device_ptr: null argument");
+    uint64_t bytes = 0;
+    if (which == GS_BUF_RGBA8) { *d_ptr = c->rgba8; return GS_OK; }
+    if (!c->have_frame) return fail(GS_ERR_NO_FRAME, "gs_device_ptr: no frame rendered");
+    return tap(c, which, d_ptr, &bytes);
+}
+
+GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
+    if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_get_stats: null argument");
+    if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+    memset(out, 0, sizeof(*out));
+    out->num_gaussians = c->n;
+    out->num_tiles = c->T;
+    out->sort_passes = c->passes;
+    out->frames = c->frames;
+    if (c->have_frame) {
+        out->num_visible = c->h_ctl->num_visible;
+        out->num_intersections = c->h_ctl->num_intersections;
+        out->num_processed = c->h_ctl->num_processed;
+        if (c->have_events) {
+            for (int i = 0; i < GS_STAGE_COUNT; ++i) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) out->stage_us[i] = ms * 1000.0f;
+            }
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[GS_STAGE_COUNT]) == hipSuccess) out->frame_us = ms * 1000.0f;
+        }
+    }
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: null ctx");
+    switch (key) {
+    case GS_OPT_BLEND_THREADS: c->blend_threads = (uint32_t)value; return GS_OK;
+    case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
+    default: break;
+    }
+    return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: bad key/value %d/%lld", key, (long long)value);
+}
+
+GS_EXPORT int32_t gs_assemble_slabs(gs_ctx* c, const void* d_slabs, const uint32_t* col_bounds, uint32_t n_slabs,
+                                    uint64_t slab_stride_bytes, void* d_image) {
+    if (!c || !d_slabs || !col_bounds || !d_image || n_slabs == 0 || n_slabs > 64)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_assemble_slabs: bad argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    uint32_t pxb[65];
+    for (uint32_t g = 0; g <= n_slabs; ++g) pxb[g] = std::min(c->frame.width, col_bounds[g] * c->frame.tile_size);
+    if (pxb[0] != 0 || pxb[n_slabs] != c->frame.width) return fail(GS_ERR_INVALID_ARGUMENT, "gs_assemble_slabs: bounds must cover the canvas");
+    HIP_TRY(hipMemcpyAsync(c->d_pxb, pxb, (n_slabs + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    gs_launch_assemble(d_slabs, d_image, c->frame.width, c->frame.height, c->d_pxb, n_slabs, slab_stride_bytes / 4, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream)); // pxb is a stack buffer
+    return GS_OK;
+}
+
+// ---- stand-alone stages ---------------------------------------------------------------------------------
+GS_EXPORT int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* values, uint64_t n, uint32_t key_bits) {
+    if (!keys && n) return fail(GS_ERR_INVALID_ARGUMENT, "gs_sort_pairs_u32: null keys");
+    if (n >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "gs_sort_pairs_u32: n >= 2^30");
+    if (key_bits == 0 || key_bits > 32) key_bits = 32;
+    if (n == 0) return GS_OK;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t passes = (key_bits + 7) / 8;
+    const size_t kb = (size_t)n * 4;
+    const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
+    const size_t st_sz = (size_t)passes * gs_sort_tiles(n) * 256 * 4;
+    uint32_t *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr;
+    void* ctl_mem = nullptr;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    int32_t rc = GS_OK;
+    auto cleanup = [&]() { hipFree(kA); hipFree(vA); hipFree(kB); hipFree(vB); hipFree(ctl_mem); };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(GS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    TRY2(hipMalloc((void**)&kA, kb)); TRY2(hipMalloc((void**)&vA, kb)); TRY2(hipMalloc((void**)&kB, kb)); TRY2(hipMalloc((void**)&vB, kb));
+    TRY2(hipMalloc(&ctl_mem, ctl_sz + st_sz));
+    TRY2(hipMemset(ctl_mem, 0, ctl_sz + st_sz));
+    TRY2(hipMemcpy(kA, keys, kb, hipMemcpyHostToDevice));
+    if (values) TRY2(hipMemcpy(vA, values, kb, hipMemcpyHostToDevice));
+    else TRY2(hipMemset(vA, 0, kb));
+    GsControl* ctl = (GsControl*)ctl_mem;
+    const uint32_t n32 = (uint32_t)n;
+    TRY2(hipMemcpy(&ctl->num_intersections, &n32, 4, hipMemcpyHostToDevice));
+    uint32_t *ok = nullptr, *ov = nullptr;
+    gs_launch_sort(kA, vA, kB, vB, ctl, &ctl->num_intersections, n32, passes, (uint32_t*)((char*)ctl_mem + ctl_sz),
+                   (uint32_t)prop.multiProcessorCount * 4, nullptr, &ok, &ov);
+    TRY2(hipGetLastError());
+    TRY2(hipDeviceSynchronize());
+    uint32_t fault = 0;
+    TRY2(hipMemcpy(&fault, &ctl->fault, 4, hipMemcpyDeviceToHost));
+    TRY2(hipMemcpy(keys, ok, kb, hipMemcpyDeviceToHost));
+    if (values) TRY2(hipMemcpy(values, ov, kb, hipMemcpyDeviceToHost));
+    cleanup();
+    if (fault) return fail(GS_ERR_DEVICE_FAULT, "gs_sort_pairs_u32: look-back spin bound exceeded");
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_exclusive_scan_u32(int32_t device, uint32_t* data, uint64_t n, uint64_t* total) {
+    if ((!data && n) || !total) return fail(GS_ERR_INVALID_ARGUMENT, "gs_exclusive_scan_u32: null argument");
+    if (n >= (1ull << 31)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_exclusive_scan_u32: n too large");
+    *total = 0;
+    if (n == 0) return GS_OK;
+    HIP_TRY(hipSetDevice(device));
+    const size_t kb = (size_t)n * 4;
+    const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
+    const size_t st_sz = ((size_t)gs_scan_blocks((uint32_t)n) + 1) * 8;
+    uint32_t *in = nullptr, *out = nullptr;
+    void* ctl_mem = nullptr;
+    int32_t rc = GS_OK;
+    auto cleanup = [&]() { hipFree(in); hipFree(out); hipFree(ctl_mem); };
+    TRY2(hipMalloc((void**)&in, kb)); TRY2(hipMalloc((void**)&out, kb)); TRY2(hipMalloc(&ctl_mem, ctl_sz + st_sz));
+    TRY2(hipMemset(ctl_mem, 0, ctl_sz + st_sz));
+    TRY2(hipMemcpy(in, data, kb, hipMemcpyHostToDevice));
+    GsControl* ctl = (GsControl*)ctl_mem;
+    gs_launch_scan(in, out, (uint32_t)n, (unsigned long long*)((char*)ctl_mem + ctl_sz), ctl, nullptr, nullptr);
+    TRY2(hipGetLastError());
+    TRY2(hipDeviceSynchronize());
+    GsControl h;
+    TRY2(hipMemcpy(&h, ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost));
+    TRY2(hipMemcpy(data, out, kb, hipMemcpyDeviceToHost));
+    cleanup();
+    if (h.fault) return fail(GS_ERR_DEVICE_FAULT, "gs_exclusive_scan_u32: look-back spin bound exceeded");
+    *total = h.num_intersections;
+    return GS_OK;
+}

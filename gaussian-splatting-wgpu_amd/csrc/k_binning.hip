@@ -1,0 +1,252 @@
+// k_binning.hip -- tile binning: exclusive scan of tile counts, (key,value) emission, tile ranges.
+//
+// Replaces
+//   ExclusiveScanner.scan + prefix_sum/block_prefix_sum/add_block_sums
+//       (reference src/exclusive_scan.ts:208-325, src/prefix_sum.wgsl:6-45, src/block_prefix_sum.wgsl:6-45,
+//        src/add_block_sums.wgsl:4-9): 3 dispatches per 262 144-element chunk + a blocking readback of I;
+//   write_tile_ids.wgsl::main (src/write_tile_ids.wgsl:18-35): one thread loops over a whole rect;
+//   compute_ranges.wgsl::main (src/compute_ranges.wgsl:5-29).
+// Here: ONE single-pass chained scan (decoupled look-back, wave64 window) that leaves I on the device,
+// a wave-cooperative load-balanced emission with fully coalesced key/value stores, and a ranges
+// kernel that writes every tile exactly once (no per-frame memset of `ranges`).
+// All three are HBM-bound integer kernels: scan 8 B/gaussian, emit 24 B/visible + 8 B/entry,
+// ranges 4 B/entry + 4 B/tile.
+#include "gs_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan, 4096 counts per workgroup, status granule = {flag:2, value:62} in one 8-byte word.
+// ------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 16
+#define SCAN_TILE (256 * SCAN_ITEMS)
+#define ST_AGG (1ull << 62)
+#define ST_PREFIX (2ull << 62)
+#define ST_MASK (3ull << 62)
+
+__global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                       uint32_t n, unsigned long long* status, GsControl* ctl,
+                                                       uint32_t* total_out) {
+    __shared__ uint32_t s_bid;
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_prefix;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_bid = atomicAdd(&ctl->scan_ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const uint32_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const uint32_t base = bid * SCAN_TILE + tid * SCAN_ITEMS;
+
+    uint32_t v[SCAN_ITEMS];
+    if (base + SCAN_ITEMS <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(counts + base);
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS / 4; ++j) {
+            const uint4 q = p[j];
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? counts[base + j] : 0u;
+    }
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) tsum += v[j];
+    const uint32_t incl = wave_incl_scan(tsum, lane);
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    uint32_t wave_excl = 0, block_total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = s_wsum[k];
+        if (k < (int)w) wave_excl += t;
+        block_total += t;
+    }
+    uint32_t run = wave_excl + incl - tsum;
+
+    if (w == 0) {
+        if (lane == 0) st_agent64(&status[bid], (bid == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long)block_total);
+        uint32_t excl = 0;
+        if (bid > 0) {
+            int look = (int)bid - 1;
+            for (;;) {
+                const int idx = look - (int)lane;
+                unsigned long long sv = ST_PREFIX; // lanes before block 0 contribute a zero prefix
+                if (idx >= 0) {
+                    uint32_t spins = 0;
+                    do {
+                        sv = ld_agent64(&status[idx]);
+                        if ((sv & ST_MASK) != 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    } while (++spins < GS_SPIN_LIMIT);
+                    if ((sv & ST_MASK) == 0) { // gave up: report, then terminate the chain
+                        ctl->fault = 1u;
+                        sv = ST_PREFIX;
+                    }
+                }
+                const unsigned long long pmask = __ballot((sv & ST_MASK) == ST_PREFIX);
+                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+                const uint32_t contrib = (lane <= first) ? (uint32_t)(sv & ~ST_MASK) : 0u;
+                excl += wave_sum(contrib);
+                if (pmask) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            if (bid > 0) st_agent64(&status[bid], ST_PREFIX | (unsigned long long)(excl + block_total));
+            s_prefix = excl;
+            if (bid == nblocks - 1) {
+                ctl->num_intersections = excl + block_total;
+                if (total_out) *total_out = excl + block_total;
+            }
+        }
+    }
+    __syncthreads();
+    run += s_prefix;
+    if (base + SCAN_ITEMS <= n) {
+        uint4* p = reinterpret_cast<uint4*>(offsets + base);
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS / 4; ++j) {
+            uint4 q;
+            q.x = run; run += v[4 * j];
+            q.y = run; run += v[4 * j + 1];
+            q.z = run; run += v[4 * j + 2];
+            q.w = run; run += v[4 * j + 3];
+            p[j] = q;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) {
+            if (base + j < n) offsets[base + j] = run;
+            run += v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Emission.  One wave owns 64 consecutive gaussians; their instances are one contiguous run of the
+// output (offsets[first] .. offsets[last]+count[last]), written 64 entries per step, lane k of a
+// step finding its gaussian by binary search in the wave's 64 local prefixes (LDS).  Key layout
+// is the reference's: (y*ntx + x)*1000 + u32(min(50*depth, 999))  (write_tile_ids.wgsl:29-31),
+// instance order y outer / x inner, gaussians in index order -- so a stable sort reproduces the
+// reference's tie order bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_cols_emit(uint32_t rx0, uint32_t rx1, const GsFrame& f, uint32_t& xa, uint32_t& wmain,
+                                               uint32_t& alias) {
+    const uint32_t hi = rx1 < f.ntx ? rx1 : f.ntx;
+    xa = rx0 > f.col0 ? rx0 : f.col0;
+    const uint32_t xb = hi < f.col1 ? hi : f.col1;
+    wmain = xb > xa ? xb - xa : 0u;
+    alias = (rx1 == f.ntx + 1u && f.col0 == 0u) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ offsets, GsFrame f,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ values,
+                                                       GsControl* ctl) {
+    __shared__ uint32_t s_pref[4][64];
+    __shared__ uint32_t s_row[4][64]; // xa | wmain<<16 | alias<<31
+    __shared__ uint32_t s_yb[4][64];  // y0 | bucket<<16
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t i = blockIdx.x * 256 + tid;
+    uint32_t cnt = 0, off = 0;
+    if (i < f.n) { cnt = counts[i]; off = offsets[i]; }
+    const uint32_t first_off = __shfl(off, 0, 64);
+    // the last lane of the wave may be past n: its off is 0; take the run end from the inclusive scan
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    const uint32_t wave_total = __shfl(incl, 63, 64);
+    if (wave_total == 0) return;
+    uint32_t row = 0, yb = 0;
+    if (cnt) {
+        const uint4 rect = gdata[(uint64_t)i * 4 + 3];
+        const float depth = __uint_as_float(gdata[(uint64_t)i * 4 + 1].w);
+        const uint32_t bucket = f2u_sat(wg_min(50.0f * depth, 999.0f));
+        uint32_t xa, wmain, alias;
+        slab_cols_emit(rect.x, rect.z, f, xa, wmain, alias);
+        row = xa | (wmain << 16) | (alias << 31);
+        yb = rect.y | (bucket << 16);
+    }
+    s_pref[w][lane] = incl - cnt; // exclusive, relative to the wave's first entry
+    s_row[w][lane] = row;
+    s_yb[w][lane] = yb;
+    // single-wave producer/consumer of these LDS rows: no workgroup barrier needed, LDS ops of one
+    // wave complete in order; the fence only stops the compiler from reordering.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t k = lane; k < wave_total; k += 64) {
+        // largest g with pref[g] <= k
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t mid = lo + step;
+            if (mid < 64 && s_pref[w][mid] <= k) lo = mid;
+        }
+        const uint32_t local = k - s_pref[w][lo];
+        const uint32_t r = s_row[w][lo], y_b = s_yb[w][lo];
+        const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
+        const uint32_t wtot = wmain + alias;
+        const uint32_t yy = local / wtot, xx = local - yy * wtot;
+        const uint32_t x = (xx < wmain) ? xa + xx : f.ntx;
+        const uint32_t y = (y_b & 0xFFFFu) + yy;
+        const uint32_t key = (y * f.ntx + x) * 1000u + (y_b >> 16);
+        const uint32_t dst = first_off + k;
+        if (dst < f.capacity) {
+            keys[dst] = key;
+            values[dst] = blockIdx.x * 256 + (w << 6) + lo;
+        } else {
+            ctl->overflow = 1u;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ranges: ranges[t] = |{ j < I : key_j/1000 <= t }| (entries with tile >= T ignored, A.6).
+// Thread j in [0, I] owns the tiles t with tile[j-1] <= t < tile[j]  (tile[-1] = 0 bound, tile[I] = T):
+// every tile is written exactly once.  Gaps longer than 64 tiles are filled by the whole wave.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restrict__ keys, const GsControl* ctl, uint32_t capacity,
+                                                         uint32_t T, uint32_t* __restrict__ ranges) {
+    uint32_t I = ctl->num_intersections;
+    if (I > capacity) I = capacity;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    // iterate whole waves so the cooperative path sees uniform control flow
+    for (uint64_t j0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); j0 <= I; j0 += stride) {
+        const uint64_t j = j0 + lane;
+        uint32_t lo = 0, hi = 0;
+        if (j <= I) {
+            lo = (j == 0) ? 0u : keys[j - 1] / 1000u;
+            hi = (j == I) ? T : keys[j] / 1000u;
+            if (lo > T) lo = T;
+            if (hi > T) hi = T;
+        }
+        const bool longgap = (hi > lo) && (hi - lo > 64u);
+        if (!longgap)
+            for (uint32_t t = lo; t < hi; ++t) ranges[t] = (uint32_t)j;
+        unsigned long long m = __ballot(longgap);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t l2 = __shfl(lo, src, 64), h2 = __shfl(hi, src, 64);
+            const uint32_t jv = (uint32_t)(j0 + src);
+            for (uint32_t t = l2 + lane; t < h2; t += 64) ranges[t] = jv;
+        }
+    }
+}
+
+// ---- host launchers --------------------------------------------------------------------------------
+uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+void gs_launch_scan(const uint32_t* counts, uint32_t* offsets, uint32_t n, unsigned long long* status, GsControl* ctl,
+                    uint32_t* total_out, hipStream_t st) {
+    const uint32_t blocks = gs_scan_blocks(n);
+    if (!blocks) return;
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(256), 0, st, counts, offsets, n, status, ctl, total_out);
+}
+void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const GsFrame& f, uint32_t* keys,
+                    uint32_t* values, GsControl* ctl, hipStream_t st) {
+    const uint32_t blocks = (f.n + 255) / 256;
+    if (!blocks) return;
+    hipLaunchKernelGGL(gs_emit_kernel, dim3(blocks), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, f, keys, values, ctl);
+}
+void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(gs_ranges_kernel, dim3(grid), dim3(256), 0, st, keys, ctl, capacity, T, ranges);
+}

@@ -1,0 +1,108 @@
+"""ctypes binding of include/gsplat/gs_abi.h (libgsplat_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "lib", "libgsplat_hip.so"))
+
+GS_FLAG_EXACT_BLEND = 0x1
+GS_FLAG_F32_TAP = 0x2
+GS_FLAG_TIMING = 0x4
+
+GS_STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend")
+
+(GS_BUF_TILE_COUNTS, GS_BUF_TILE_OFFSETS, GS_BUF_GAUSSIAN_DATA, GS_BUF_KEYS_UNSORTED, GS_BUF_VALUES_UNSORTED, GS_BUF_KEYS,
+ GS_BUF_VALUES, GS_BUF_RANGES, GS_BUF_RGBA8, GS_BUF_RGB_F32) = range(10)
+
+GS_OPT_BLEND_THREADS = 1
+GS_OPT_PERSISTENT_GRID = 2
+
+# every symbol include/gsplat/gs_abi.h declares
+ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
+               "gs_render", "gs_render_debug", "gs_render_to", "gs_wait", "gs_read_rgba8", "gs_read_buffer", "gs_device_ptr",
+               "gs_get_stats", "gs_set_option", "gs_slab_width", "gs_assemble_slabs", "gs_sort_pairs_u32",
+               "gs_exclusive_scan_u32")
+
+
+class GsConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("tile_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("col_begin", ctypes.c_uint32),
+                ("col_end", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("max_intersections", ctypes.c_uint64),
+                ("stream", ctypes.c_void_p)]
+
+
+class GsStats(ctypes.Structure):
+    _fields_ = [("num_gaussians", ctypes.c_uint64), ("num_visible", ctypes.c_uint64), ("num_intersections", ctypes.c_uint64),
+                ("num_processed", ctypes.c_uint64), ("num_tiles", ctypes.c_uint32), ("sort_passes", ctypes.c_uint32),
+                ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float)]
+
+
+class GsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gsplat error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libgsplat_hip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libgsplat_hip.so not built: run `python gaussian-splatting-wgpu_amd/csrc/build.py` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, i32, u32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32
+    L.gs_last_error.restype = ctypes.c_char_p
+    L.gs_abi_version.restype = i32
+    L.gs_create.argtypes = [ctypes.POINTER(GsConfig), ctypes.POINTER(vp)]
+    L.gs_destroy.argtypes = [vp]
+    L.gs_upload_splats.argtypes = [vp, vp, u64]
+    L.gs_upload_splats_device.argtypes = [vp, vp, u64]
+    L.gs_render.argtypes = [vp, vp]
+    L.gs_render_debug.argtypes = [vp, vp]
+    L.gs_render_to.argtypes = [vp, vp, vp]
+    L.gs_wait.argtypes = [vp]
+    L.gs_read_rgba8.argtypes = [vp, vp, u64]
+    L.gs_read_buffer.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64)]
+    L.gs_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    L.gs_get_stats.argtypes = [vp, ctypes.POINTER(GsStats)]
+    L.gs_set_option.argtypes = [vp, i32, ctypes.c_int64]
+    L.gs_slab_width.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.gs_assemble_slabs.argtypes = [vp, vp, ctypes.POINTER(u32), u32, u64, vp]
+    L.gs_sort_pairs_u32.argtypes = [i32, vp, vp, u64, u32]
+    L.gs_exclusive_scan_u32.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
+    for name in ABI_SYMBOLS:
+        if name != "gs_last_error":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise GsError(rc, load().gs_last_error().decode("utf-8", "replace"))
+
+
+def sort_pairs(keys, values=None, key_bits=32, device=0):
+    """GPUSorter.sort (radix_sort/sort.ts:341-350) on host arrays; returns sorted copies."""
+    k = np.array(keys, dtype=np.uint32, copy=True)
+    v = None if values is None else np.array(values, dtype=np.uint32, copy=True)
+    check(load().gs_sort_pairs_u32(device, k.ctypes.data, None if v is None else v.ctypes.data, k.size, key_bits))
+    return k, v
+
+
+def exclusive_scan(data, device=0):
+    """ExclusiveScanner.scan (exclusive_scan.ts:208-325): returns (offsets, total)."""
+    d = np.array(data, dtype=np.uint32, copy=True)
+    total = ctypes.c_uint64(0)
+    check(load().gs_exclusive_scan_u32(device, d.ctypes.data, d.size, ctypes.byref(total)))
+    return d, int(total.value)

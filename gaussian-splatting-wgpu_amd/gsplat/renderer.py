@@ -1,0 +1,151 @@
+"""Python mirror of the reference's ``Renderer`` (renderer.ts:35-594) on top of the C ABI.
+
+Same constructor shape -- Renderer(canvas, interactiveCamera, device, gaussians, tileSize) -- where
+``canvas`` is anything with width/height, ``device`` is a HIP device ordinal and ``gaussians`` has
+``numGaussians`` and ``gaussiansBuffer`` (the 320-byte records PackedGaussians builds).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+from ._abi import GsConfig, GsStats, check
+
+
+class Canvas:
+    def __init__(self, width, height):
+        self.width = int(width)
+        self.height = int(height)
+
+
+class PackedGaussians:
+    """Holds the packed 320-byte records (ply.ts:32-47 fields the renderer consumes)."""
+
+    def __init__(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 80)
+        self.numGaussians = rec.shape[0]
+        self.gaussiansBuffer = rec
+        self.sphericalHarmonicsDegree = 3
+
+
+class InteractiveCamera:
+    """camera.ts:193-308 without the DOM callbacks: dirty flag + camera."""
+
+    def __init__(self, camera):
+        self._camera = camera
+        self._dirty = True
+
+    def setNewCamera(self, camera):
+        self._camera = camera
+        self._dirty = True
+
+    def isDirty(self):
+        return self._dirty
+
+    def getCamera(self):
+        self._dirty = False
+        return self._camera
+
+
+class Renderer:
+    def __init__(self, canvas, interactiveCamera, device, gaussians, tileSize=16, *, flags=0, cols=None,
+                 max_intersections=0, stream=None):
+        self.canvas = canvas
+        self.interactiveCamera = interactiveCamera
+        self.device = int(device)
+        self.tileSize = int(tileSize)
+        self.numGaussians = gaussians.numGaussians
+        self.numIntersections = 0
+        self.numFrames = 0
+        self._L = _abi.load()
+        cfg = GsConfig()
+        cfg.struct_size = ctypes.sizeof(GsConfig)
+        cfg.width, cfg.height, cfg.tile_size = canvas.width, canvas.height, self.tileSize
+        cfg.device = self.device
+        cfg.col_begin, cfg.col_end = cols if cols is not None else (0, 0)
+        cfg.flags = flags
+        cfg.max_intersections = int(max_intersections)
+        cfg.stream = stream
+        self._ctx = ctypes.c_void_p()
+        check(self._L.gs_create(ctypes.byref(cfg), ctypes.byref(self._ctx)))
+        self.flags = flags
+        buf = gaussians.gaussiansBuffer
+        if hasattr(buf, "data_ptr"):  # a device tensor: no PCIe copy
+            check(self._L.gs_upload_splats_device(self._ctx, buf.data_ptr(), self.numGaussians))
+        else:
+            arr = np.ascontiguousarray(buf, dtype=np.float32)
+            check(self._L.gs_upload_splats(self._ctx, arr.ctypes.data, self.numGaussians))
+        x0, w = ctypes.c_uint32(), ctypes.c_uint32()
+        check(self._L.gs_slab_width(self._ctx, ctypes.byref(x0), ctypes.byref(w)))
+        self.slab_x0, self.slab_width = x0.value, w.value
+
+    # -- frame -------------------------------------------------------------------------------------
+    def render_uniforms(self, uniforms, debug=False, out_ptr=None):
+        u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(40)
+        if out_ptr is not None:
+            check(self._L.gs_render_to(self._ctx, u.ctypes.data, out_ptr))
+        elif debug:
+            check(self._L.gs_render_debug(self._ctx, u.ctypes.data))
+        else:
+            check(self._L.gs_render(self._ctx, u.ctypes.data))
+        self.numFrames += 1
+
+    def animate(self, debug=False):
+        """One Renderer.animate() tick (renderer.ts:349-593): renders only when the camera is dirty."""
+        if self._ctx is None:
+            raise RuntimeError("renderer destroyed")
+        if not self.interactiveCamera.isDirty():
+            return False
+        cam = self.interactiveCamera.getCamera()
+        self.render_uniforms(cam.uniforms(self.canvas.width, self.canvas.height), debug=debug)
+        return True
+
+    def wait(self):
+        check(self._L.gs_wait(self._ctx))
+
+    def set_option(self, key, value):
+        check(self._L.gs_set_option(self._ctx, key, int(value)))
+
+    # -- outputs -----------------------------------------------------------------------------------
+    def read_rgba8(self):
+        out = np.empty((self.canvas.height, self.slab_width, 4), dtype=np.uint8)
+        check(self._L.gs_read_rgba8(self._ctx, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_buffer(self, which, dtype=np.uint32):
+        n = ctypes.c_uint64()
+        check(self._L.gs_read_buffer(self._ctx, which, None, 0, ctypes.byref(n)))
+        out = np.empty(n.value // np.dtype(dtype).itemsize, dtype=dtype)
+        if n.value:
+            check(self._L.gs_read_buffer(self._ctx, which, out.ctypes.data, out.nbytes, None))
+        return out
+
+    def device_ptr(self, which):
+        p = ctypes.c_void_p()
+        check(self._L.gs_device_ptr(self._ctx, which, ctypes.byref(p)))
+        return p.value
+
+    def stats(self):
+        s = GsStats()
+        check(self._L.gs_get_stats(self._ctx, ctypes.byref(s)))
+        d = {k: getattr(s, k) for k in ("num_gaussians", "num_visible", "num_intersections", "num_processed", "num_tiles",
+                                        "sort_passes", "frames", "frame_us")}
+        d["stage_us"] = {n: s.stage_us[i] for i, n in enumerate(_abi.GS_STAGE_NAMES)}
+        self.numIntersections = d["num_intersections"]
+        return d
+
+    def assemble(self, d_slabs_ptr, col_bounds, slab_stride_bytes, d_image_ptr):
+        cb = (ctypes.c_uint32 * len(col_bounds))(*col_bounds)
+        check(self._L.gs_assemble_slabs(self._ctx, d_slabs_ptr, cb, len(col_bounds) - 1, slab_stride_bytes, d_image_ptr))
+
+    def destroy(self):
+        """Renderer.destroy (renderer.ts:90-94); safe to call twice and before the first frame."""
+        if self._ctx is not None:
+            check(self._L.gs_destroy(self._ctx))
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

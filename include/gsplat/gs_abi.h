@@ -1,0 +1,168 @@
+/*
+ * gs_abi.h -- C ABI of the MI355X-native forward Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of ldyken53/gaussian-splatting-wgpu: everything
+ * `Renderer` (src/renderer.ts:96-102,349-593) asks of WebGPU per scene and per frame goes through
+ * the entry points below.  Plain C: opaque handle, plain pointers and sizes, int32 status codes,
+ * no C++ types, no exceptions, no torch types.  The reference has no FFI of its own (it is a
+ * browser app); the N-API binding a Node host uses is gaussian-splatting-wgpu_amd/csrc/napi and
+ * the binding stubs for other hosts are in INTEGRATION.md.
+ *
+ * Threading: a gs_ctx is not re-entrant (one frame in flight per ctx); different ctxs may be used
+ * from different threads.  All device work of a ctx is ordered on one HIP stream.
+ * Ownership: the ctx owns every device allocation; host pointers passed in are copied before the
+ * call returns; output host buffers are caller-allocated.
+ */
+#ifndef GSPLAT_GS_ABI_H
+#define GSPLAT_GS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+/* ---- status codes (every function returns one; message via gs_last_error) ------------------ */
+#define GS_OK 0
+#define GS_ERR_INVALID_ARGUMENT (-1) /* null pointer, bad size, unsupported tile size ...           */
+#define GS_ERR_NO_DEVICE (-2)        /* no HIP device / HIP runtime failure at create             */
+#define GS_ERR_HIP (-3)              /* a HIP call failed; gs_last_error has hipGetErrorString      */
+#define GS_ERR_OUT_OF_MEMORY (-4)
+#define GS_ERR_NO_SCENE (-5)         /* gs_render before gs_upload_splats                           */
+#define GS_ERR_NO_FRAME (-6)         /* read-back before any gs_render                              */
+#define GS_ERR_DEVICE_FAULT (-7)     /* an in-kernel bounded spin gave up (decoupled look-back)     */
+#define GS_ERR_CAPACITY (-8)         /* intersections exceed the hard limit (2^30, radix_sort.wgsl:220-221) */
+
+/* ---- byte layouts fixed by the reference ------------------------------------------------------
+ * splat record   320 B  ply.ts:190-198 / process_gaussians.wgsl:1-7
+ *     pos f32x3 @0, log_scale f32x3 @16, rot f32x4 (r,x,y,z) @32, opacity_logit f32 @48,
+ *     sh 16 x (f32x3, stride 16) @64
+ * uniform block  160 B  renderer.ts:15-24,371-392 / process_gaussians.wgsl:16-25
+ *     view mat4 col-major @0, proj(=P*V) @64, cam_pos f32x3 @128, tan_fovx @140, tan_fovy @144,
+ *     focal_x @148, focal_y @152, scale_modifier @156
+ * GaussianData    64 B  process_gaussians.wgsl:8-15
+ *     uv f32x2 @0, conic f32x3 @16, depth @28, color f32x3 @32, opacity @44, rect u32x4 @48
+ */
+#define GS_SPLAT_RECORD_BYTES 320
+#define GS_UNIFORM_BYTES 160
+#define GS_GAUSSIAN_DATA_BYTES 64
+
+/* ---- configuration: what `new Renderer(canvas, camera, device, gaussians, tileSize)` fixes ---- */
+#define GS_FLAG_EXACT_BLEND 0x1u /* blend with the canonical (as-written, unfused) f32 arithmetic: bit-equal to
+                                    the CPU oracle; default is fused f32 + hardware exp2 (<=1e-4 per channel)  */
+#define GS_FLAG_F32_TAP 0x2u     /* also keep the un-quantised f32 RGB accumulators (GS_BUF_RGB_F32)            */
+#define GS_FLAG_TIMING 0x4u      /* bracket every stage with hipEvents; gs_get_stats returns stage microseconds */
+
+typedef struct gs_config {
+    uint32_t struct_size;       /* = sizeof(gs_config); lets the struct grow                                     */
+    uint32_t width, height;     /* canvas.width / canvas.height (renderer.ts:157,199,366)                       */
+    uint32_t tile_size;         /* 8, 16 or 32 (index.html:20-24, app.ts:29,45)                                 */
+    int32_t device;             /* HIP device ordinal                                                           */
+    uint32_t col_begin, col_end;/* tile-column slab owned by this ctx, [begin,end); 0,0 = whole screen          */
+    uint32_t flags;             /* GS_FLAG_*                                                                     */
+    uint64_t max_intersections; /* capacity hint for the (key,value) arrays; 0 = derive from the scene         */
+    void* stream;               /* hipStream_t to run on; NULL = the ctx creates its own                        */
+} gs_config;
+
+/* ---- per-frame statistics (the reference only console.logs these: renderer.ts:406-590) ------- */
+enum {
+    GS_STAGE_PREPROCESS = 0, /* process_gaussians.wgsl::main                       */
+    GS_STAGE_SCAN = 1,       /* ExclusiveScanner.scan (exclusive_scan.ts:208-325)  */
+    GS_STAGE_EMIT = 2,       /* write_tile_ids.wgsl::main                          */
+    GS_STAGE_SORT = 3,       /* GPUSorter.sort (sort.ts:341-350)                   */
+    GS_STAGE_RANGES = 4,     /* compute_ranges.wgsl::main                          */
+    GS_STAGE_BLEND = 5,      /* compute_tiles.wgsl::main (+ the render.wgsl blit, which is the identity) */
+    GS_STAGE_COUNT = 6
+};
+
+typedef struct gs_stats {
+    uint64_t num_gaussians;       /* N                                                        */
+    uint64_t num_visible;         /* gaussians that passed the cull (tile count > 0)          */
+    uint64_t num_intersections;   /* I: what ExclusiveScanner.scan returns (renderer.ts:419)  */
+    uint64_t num_processed;       /* list entries staged by the blend before tile early-exit  */
+    uint32_t num_tiles;           /* T over the whole canvas                                  */
+    uint32_t sort_passes;         /* 8-bit radix passes executed                              */
+    uint64_t frames;              /* frames rendered by this ctx                              */
+    float stage_us[GS_STAGE_COUNT]; /* per-stage device time of the last frame (GS_FLAG_TIMING) */
+    float frame_us;               /* first kernel start -> last kernel end (GS_FLAG_TIMING)    */
+} gs_stats;
+
+/* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */
+enum {
+    GS_BUF_TILE_COUNTS = 0,   /* u32[N]     tileCountBuffer                                   */
+    GS_BUF_TILE_OFFSETS = 1,  /* u32[N]     tileOffsetBuffer after the scan                   */
+    GS_BUF_GAUSSIAN_DATA = 2, /* 64 B x N   gaussianDataBuffer (culled records are all-zero)  */
+    GS_BUF_KEYS_UNSORTED = 3, /* u32[I]     tile_ids as written by write_tile_ids (needs gs_render_debug) */
+    GS_BUF_VALUES_UNSORTED = 4,
+    GS_BUF_KEYS = 5,          /* u32[I]     sorted tileIDBuffer                                */
+    GS_BUF_VALUES = 6,        /* u32[I]     sorted gaussianIDBuffer                            */
+    GS_BUF_RANGES = 7,        /* u32[T]     rangesBuffer                                       */
+    GS_BUF_RGBA8 = 8,         /* u8[H][Wslab][4] renderTarget (rgba8unorm), this ctx's slab    */
+    GS_BUF_RGB_F32 = 9        /* f32[H][Wslab][3] (GS_FLAG_F32_TAP)                            */
+};
+
+typedef struct gs_ctx gs_ctx;
+
+/* Thread-local message of the last failing call on this thread. */
+const char* gs_last_error(void);
+int32_t gs_abi_version(void);
+
+/* Replaces `new Renderer(...)` buffer/pipeline setup (renderer.ts:96-324). */
+int32_t gs_create(const gs_config* cfg, gs_ctx** out);
+/* Replaces Renderer.destroy()/destroyImpl (renderer.ts:90-94,326-347).  Safe before the first frame. */
+int32_t gs_destroy(gs_ctx* ctx);
+
+/* Replaces the pointDataBuffer upload (renderer.ts:130-137): takes the exact bytes of
+ * PackedGaussians.gaussiansBuffer (ply.ts:204-220), n records of 320 B, host memory.  The records
+ * are re-laid-out on the device; the caller's buffer is not referenced after return. */
+int32_t gs_upload_splats(gs_ctx* ctx, const void* aos320, uint64_t n);
+/* Same, from a device pointer (no PCIe copy). */
+int32_t gs_upload_splats_device(gs_ctx* ctx, const void* d_aos320, uint64_t n);
+
+/* Replaces one Renderer.animate() frame (renderer.ts:349-593): enqueues the whole frame for the
+ * 160-byte uniform block and returns without waiting for the device. */
+int32_t gs_render(gs_ctx* ctx, const void* uniforms160);
+/* As gs_render, additionally keeping the unsorted (key,value) arrays for GS_BUF_*_UNSORTED. */
+int32_t gs_render_debug(gs_ctx* ctx, const void* uniforms160);
+/* As gs_render, writing the rgba8 slab image straight into caller-owned DEVICE memory
+ * (u8[height][slab_width][4]); used to render into a collective's send buffer. */
+int32_t gs_render_to(gs_ctx* ctx, const void* uniforms160, void* d_rgba8);
+/* Blocks until the frame is complete (the reference awaits onSubmittedWorkDone 8x per frame).
+ * Reports device-side faults; grows the (key,value) capacity and re-renders if the frame overflowed. */
+int32_t gs_wait(gs_ctx* ctx);
+
+/* Replaces the blit to the canvas (render.wgsl, renderer.ts:549-574): copies the finished rgba8
+ * image of this ctx's slab to host memory; size must be height*slab_width*4. */
+int32_t gs_read_rgba8(gs_ctx* ctx, void* dst, uint64_t size);
+/* Copies one debug tap to host memory.  *written receives the byte count; dst may be NULL to query it. */
+int32_t gs_read_buffer(gs_ctx* ctx, int32_t which, void* dst, uint64_t size, uint64_t* written);
+/* Device address of a tap (valid until the next gs_render / gs_destroy), for zero-copy consumers. */
+int32_t gs_device_ptr(gs_ctx* ctx, int32_t which, void** d_ptr);
+int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
+/* Tuning knobs that do not change results. */
+#define GS_OPT_BLEND_THREADS 1   /* threads per tile in the blend (tile 16: 64/128/256; tile 32: 256/1024); 0 = default */
+#define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
+int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
+/* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
+int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);
+
+/* Multi-GPU presentation: scatter `n_slabs` gathered slab images (slab g = u8[height][w_g][4]) into one
+ * row-major u8[height][width][4] DEVICE image.  col_bounds (host) has n_slabs+1 tile-column boundaries.
+ * slab_stride_bytes = distance between consecutive slabs in d_slabs (what an all-gather of equally
+ * sized, padded send buffers produces); 0 = slabs tightly packed in rank order.  Runs on the ctx stream. */
+int32_t gs_assemble_slabs(gs_ctx* ctx, const void* d_slabs, const uint32_t* col_bounds, uint32_t n_slabs,
+                          uint64_t slab_stride_bytes, void* d_image);
+
+/* ---- stand-alone stages, mirroring the reference's reusable classes ---------------------------- */
+/* GPUSorter.sort (radix_sort/sort.ts:341-350): stable ascending sort of n u32 keys with u32 payloads,
+ * host buffers, in place.  values may be NULL (keys only, as testSort does: radix_sort/utils.ts:55-81). */
+int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* values, uint64_t n, uint32_t key_bits);
+/* ExclusiveScanner.scan (exclusive_scan.ts:208-325): in-place exclusive scan of n u32, returns the total. */
+int32_t gs_exclusive_scan_u32(int32_t device, uint32_t* data, uint64_t n, uint64_t* total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_GS_ABI_H */
