@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the forward splat-render path on N MI355X (BASELINE.json metric).
+
+A "step" is one whole frame (process_gaussians -> scan -> write_tile_ids -> radix sort -> ranges ->
+blend; for N > 1 plus the RCCL all-gather of the per-rank tile-column slabs and their assembly) for
+a camera that moves every step along a fixed orbit, with the splats already resident in HBM.
+
+    python bench.py                       # N=1, config B: 6.1 M splats @ 1920x1080
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  The per-stage device times come from hipEvents that the library
+records on its own stream inside the timed region (GS_FLAG_TIMING); the CPU oracle is timed on a
+bounded sample of the same workload on rank 0 at N=1 (a reported baseline, not a target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-wgpu_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+VALU_PEAK_TFLOPS = 157.3   # peak vector fp32 (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # BASELINE.json configs[1], [2], [4]; "bicycle-like" synthetic, no real scene offline
+    "B": dict(n=6_100_000, width=1920, height=1080, name="bicycle-like synthetic 6.1M gaussians @1920x1080"),
+    "C": dict(n=6_100_000, width=3840, height=2160, name="bicycle-like synthetic 6.1M gaussians @3840x2160"),
+    "E": dict(n=50_000_000, width=1920, height=1080, name="bicycle-like synthetic 50M gaussians @1920x1080"),
+    "A": dict(n=10_000, width=256, height=256, name="bicycle-like synthetic 10k gaussians @256x256"),
+}
+
+
+def algorithmic_bytes(st, W, H, T):
+    """SURVEY.md 8(d) per-frame algorithmic bytes, per stage."""
+    N, Nv, I, Ip, p = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"]
+    return {
+        "preprocess": 12 * (N - Nv) + 236 * Nv + 4 * N + 56 * Nv,
+        "scan": 8 * N,
+        "emit": 24 * Nv + 8 * I,
+        "sort": (4 + 16 * p) * I,
+        "ranges": 4 * I + 4 * T,
+        "blend": 40 * Ip + 4 * W * H,
+    }
+
+
+def cpu_baseline(n_full, W, H, seed, sample_n):
+    """Times the CPU oracle (oracle/gs_oracle.c, OpenMP) on a bounded sample of the same workload."""
+    from gsplat import synth
+    from oracle import gs_oracle
+    gs_oracle.build()
+    n = min(sample_n, n_full)
+    splats = synth.bicycle_like(n, seed)
+    u = synth.orbit_camera(0, W, H).uniforms(W, H)
+    cores = gs_oracle.get_num_threads()
+    t0 = time.perf_counter()
+    out = gs_oracle.render(splats, u, W, H, 16, want_f32=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": 1.0 / dt, "unit": "frames/s (on the sample)", "cores": cores, "kind": "port",
+        "sample": "1 frame, first %d of %d gaussians of the numpy-seeded scene, same %dx%d orbit camera; "
+                  "%d intersections; CPU restatement of the reference pipeline (oracle/gs_oracle.c, OpenMP)"
+                  % (n, n_full, W, H, out["num_intersections"]),
+        "seconds": dt,
+        "linear_extrapolation_full_scene": (1.0 / dt) * n / n_full,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
+    ap.add_argument("--n", type=int, default=0, help="override the gaussian count")
+    ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--blend-threads", type=int, default=0)
+    ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import gsplat
+    from gsplat import _abi, synth
+
+    cfg = dict(CONFIGS[args.config])
+    if args.n:
+        cfg["n"] = args.n
+    N, W, H, ts = cfg["n"], cfg["width"], cfg["height"], args.tile
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    seed = synth.BASE_SEED + {"A": 0, "B": 1, "C": 2, "E": 4}[args.config]
+    ntx = int(np.ceil(np.float32(W) / np.float32(ts)))
+    bounds = [ntx * g // world for g in range(world + 1)]  # tile-column slabs
+    cols = (bounds[rank], bounds[rank + 1])
+
+    splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
+    flags = 0 if args.no_timing else _abi.GS_FLAG_TIMING
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+    pg.numGaussians, pg.gaussiansBuffer, pg.sphericalHarmonicsDegree = N, splats, 3
+    r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags, cols=cols if world > 1 else None,
+                        stream=stream)
+    del splats, pg
+    torch.cuda.empty_cache()
+    if args.blend_threads:
+        r.set_option(_abi.GS_OPT_BLEND_THREADS, args.blend_threads)
+
+    uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
+    slab_w_max = max(min(W, bounds[g + 1] * ts) - bounds[g] * ts for g in range(world))
+    if world > 1:
+        send = torch.zeros((H * slab_w_max * 4,), dtype=torch.uint8, device=dev)
+        gathered = torch.zeros((world * H * slab_w_max * 4,), dtype=torch.uint8, device=dev)
+        image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+
+    def step(k):
+        u = uniforms[k % 64]
+        if world == 1:
+            r.render_uniforms(u)
+        else:
+            r.render_uniforms(u, out_ptr=send.data_ptr())
+            dist.all_gather_into_tensor(gathered, send)  # one RCCL gather of the slabs over xGMI
+            if rank == 0:
+                r.assemble(gathered.data_ptr(), bounds, H * slab_w_max * 4, image.data_ptr())
+
+    def sync():
+        r.wait()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    r.set_option(_abi.GS_OPT_RESET_TIMING, 0)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = r.stats()
+
+    if world > 1:
+        # whole-frame statistics are the sums over the slabs
+        v = torch.tensor([st["num_visible"], st["num_intersections"], st["num_processed"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(v)
+        tot_vis, tot_I, tot_Ip = (int(x) for x in v.tolist())
+    else:
+        tot_vis, tot_I, tot_Ip = st["num_visible"], st["num_intersections"], st["num_processed"]
+
+    if rank == 0:
+        T = st["num_tiles"]
+        line = {
+            "metric": "frames/sec", "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
+                       "parallelism": "tile-column slabs x%d + all-gather" % world if world > 1 else "single GPU",
+                       "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip,
+                       "sort_passes": st["sort_passes"], "camera": "64-step orbit, moved every frame"},
+        }
+        if not args.no_timing and st["frames_timed"]:
+            ab = algorithmic_bytes(st, W, H, T)
+            stages = {}
+            for name, us in st["stage_us_mean"].items():
+                gbs = ab[name] / (us * 1e-6) / 1e9 if us > 0 else 0.0
+                stages[name] = {"us": round(us, 2), "alg_bytes": int(ab[name]), "GBps": round(gbs, 1),
+                                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+            dom = max(st["stage_us_mean"], key=lambda k_: st["stage_us_mean"][k_])
+            dus = st["stage_us_mean"][dom]
+            ach = ab[dom] / (dus * 1e-6) / 1e9
+            line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                "launch_us": round(dus, 2), "frames_timed": st["frames_timed"],
+                                "rank0_slab_only": world > 1}
+            bus = st["stage_us_mean"]["blend"]
+            if bus > 0:
+                flops = 24.0 * (ts * ts) * st["num_processed"]  # 22 flop + 1 exp (counted 2) per pixel x staged entry
+                line["roofline"]["blend_valu"] = {"achieved": round(flops / (bus * 1e-6) / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
+                                                  "unit": "TFLOP/s", "frac": round(flops / (bus * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+            line["stages"] = stages
+            line["frame_us_device"] = round(st["frame_us_mean"], 2)
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(N, W, H, seed, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    r.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,7 @@ static int32_t fail(int32_t code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                                             \
     } while (0)
 
+#define GS_EV_RING 256
 struct gs_ctx {
     gs_config cfg{};
     hipStream_t stream = nullptr;
@@ -71,8 +72,9 @@ struct gs_ctx {
     uint32_t* rgba8 = nullptr;
     float* rgbf = nullptr;
     uint32_t* d_pxb = nullptr; // assemble: pixel boundaries
-    hipEvent_t ev[GS_STAGE_COUNT + 1] = {};
+    hipEvent_t ev[GS_EV_RING][GS_STAGE_COUNT + 1] = {}; // ring of per-frame stage brackets (GS_FLAG_TIMING)
     bool have_events = false;
+    uint64_t timed_from = 0; // first frame index included in the stage means
     // frame state
     bool have_frame = false, pending = false, last_debug = false;
     void* last_ext = nullptr;
@@ -171,7 +173,8 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     memset(c->h_ctl, 0, sizeof(GsControl));
     HIP_TRY(hipMalloc((void**)&c->d_pxb, 65 * 4));
     if (cfg->flags & GS_FLAG_TIMING) {
-        for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+        for (auto& row : c->ev)
+            for (auto& e : row) HIP_TRY(hipEventCreate(&e));
         c->have_events = true;
     }
     *out = c;
@@ -186,7 +189,9 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb);
     if (c->h_ctl) hipHostFree(c->h_ctl);
-    if (c->have_events) for (auto& e : c->ev) hipEventDestroy(e);
+    if (c->have_events)
+        for (auto& row : c->ev)
+            for (auto& e : row) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return GS_OK;
@@ -247,7 +252,7 @@ GS_EXPORT int32_t gs_upload_splats(gs_ctx* c, const void* aos, uint64_t n) {
 }
 
 static inline void mark(gs_ctx* c, int i) {
-    if (c->have_events) hipEventRecord(c->ev[i], c->stream);
+    if (c->have_events) hipEventRecord(c->ev[c->frames % GS_EV_RING][i], c->stream);
 }
 
 static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8) {
@@ -323,7 +328,7 @@ GS_EXPORT int32_t gs_wait(gs_ctx* c) {
         hipFree(c->keysU); hipFree(c->valsU); c->keysU = c->valsU = nullptr;
         int32_t rc = alloc_kv(c, want);
         if (rc != GS_OK) return rc;
-        c->frames--;
+        c->frames--; // the re-render reuses the frame's slot in the event ring
         rc = enqueue_frame(c, c->last_u, c->last_debug, c->last_ext);
         if (rc != GS_OK) return rc;
     }
@@ -400,13 +405,37 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
         out->num_processed = c->h_ctl->num_processed;
-        if (c->have_events) {
-            for (int i = 0; i < GS_STAGE_COUNT; ++i) {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) out->stage_us[i] = ms * 1000.0f;
+        if (c->have_events && c->frames > 0) {
+            const uint64_t last = c->frames - 1;
+            uint64_t first = c->timed_from;
+            if (last + 1 > GS_EV_RING && first < last + 1 - GS_EV_RING) first = last + 1 - GS_EV_RING;
+            if (first > last) first = last;
+            double sum[GS_STAGE_COUNT + 1] = {0};
+            uint32_t cnt = 0;
+            for (uint64_t fr = first; fr <= last; ++fr) {
+                hipEvent_t* e = c->ev[fr % GS_EV_RING];
+                float ms = 0, tot = 0;
+                bool ok = true;
+                float st[GS_STAGE_COUNT];
+                for (int i = 0; i < GS_STAGE_COUNT && ok; ++i) {
+                    ok = hipEventElapsedTime(&ms, e[i], e[i + 1]) == hipSuccess;
+                    st[i] = ms * 1000.0f;
+                }
+                ok = ok && hipEventElapsedTime(&tot, e[0], e[GS_STAGE_COUNT]) == hipSuccess;
+                if (!ok) continue;
+                for (int i = 0; i < GS_STAGE_COUNT; ++i) sum[i] += st[i];
+                sum[GS_STAGE_COUNT] += tot * 1000.0f;
+                ++cnt;
+                if (fr == last) {
+                    for (int i = 0; i < GS_STAGE_COUNT; ++i) out->stage_us[i] = st[i];
+                    out->frame_us = tot * 1000.0f;
+                }
             }
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[GS_STAGE_COUNT]) == hipSuccess) out->frame_us = ms * 1000.0f;
+            out->frames_timed = cnt;
+            if (cnt) {
+                for (int i = 0; i < GS_STAGE_COUNT; ++i) out->stage_us_mean[i] = (float)(sum[i] / cnt);
+                out->frame_us_mean = (float)(sum[GS_STAGE_COUNT] / cnt);
+            }
         }
     }
     return GS_OK;
@@ -417,6 +446,7 @@ GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     switch (key) {
     case GS_OPT_BLEND_THREADS: c->blend_threads = (uint32_t)value; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
+    case GS_OPT_RESET_TIMING: c->timed_from = c->frames; return GS_OK;
     default: break;
     }
     return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: bad key/value %d/%lld", key, (long long)value);

@@ -21,6 +21,7 @@ GS_STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend")
 
 GS_OPT_BLEND_THREADS = 1
 GS_OPT_PERSISTENT_GRID = 2
+GS_OPT_RESET_TIMING = 3
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
@@ -39,7 +40,8 @@ class GsConfig(ctypes.Structure):
 class GsStats(ctypes.Structure):
     _fields_ = [("num_gaussians", ctypes.c_uint64), ("num_visible", ctypes.c_uint64), ("num_intersections", ctypes.c_uint64),
                 ("num_processed", ctypes.c_uint64), ("num_tiles", ctypes.c_uint32), ("sort_passes", ctypes.c_uint32),
-                ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float)]
+                ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float),
+                ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32)]
 
 
 class GsError(RuntimeError):

@@ -80,3 +80,30 @@ def orbit_camera(step, W, H, steps=64, radius=4.5, height=1.0, znear=0.2, zfar=1
     focal = float(W)
     fovx, fovy = focal2fov(focal, W), focal2fov(focal, H)
     return Camera(H, W, look_at_view(eye), get_projection_matrix(znear, zfar, fovx, fovy), focal, focal, 1.0)
+
+
+def bicycle_like_torch(n, seed=BASE_SEED, device="cuda"):
+    """Same distribution as bicycle_like, generated straight into device memory with torch's
+    generator (bench.py: avoids a minute of host RNG and a 2 GB PCIe copy at 6.1 M splats).
+    Deterministic for a given seed on a given torch build; NOT bit-identical to the numpy scene."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    n = int(n)
+    out = torch.zeros((n, SPLAT_FLOATS), dtype=torch.float32, device=device)
+    sel = torch.rand(n, generator=g, device=device)
+    fg = torch.randn((n, 3), generator=g, device=device) * 1.5
+    r = fg.norm(dim=1).clamp_min(1e-12)
+    fg = fg * torch.clamp(4.0 / r, max=1.0)[:, None]
+    d = torch.randn((n, 3), generator=g, device=device)
+    d = d / d.norm(dim=1).clamp_min(1e-12)[:, None]
+    rad = 4.0 + 21.0 * torch.rand(n, generator=g, device=device)
+    pos = torch.where((sel < 0.7)[:, None], fg, d * rad[:, None])
+    dist = pos.norm(dim=1).clamp_min(1.0)
+    out[:, 0:3] = pos
+    out[:, 4:7] = torch.log(0.004 * dist)[:, None] + 0.8 * torch.randn((n, 3), generator=g, device=device)
+    out[:, 8:12] = torch.randn((n, 4), generator=g, device=device)
+    out[:, 12] = 1.0 + 2.5 * torch.randn(n, generator=g, device=device)
+    out[:, 16:19] = 0.5 + torch.randn((n, 3), generator=g, device=device)
+    out[:, 20:80].view(n, 15, 4)[:, :, 0:3] = 0.08 * torch.randn((n, 15, 3), generator=g, device=device)
+    return out

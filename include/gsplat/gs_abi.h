@@ -87,6 +87,9 @@ typedef struct gs_stats {
     uint64_t frames;              /* frames rendered by this ctx                              */
     float stage_us[GS_STAGE_COUNT]; /* per-stage device time of the last frame (GS_FLAG_TIMING) */
     float frame_us;               /* first kernel start -> last kernel end (GS_FLAG_TIMING)    */
+    float stage_us_mean[GS_STAGE_COUNT]; /* mean over the frames since GS_OPT_RESET_TIMING (at most the last 256) */
+    float frame_us_mean;
+    uint32_t frames_timed;        /* frames the means cover                                    */
 } gs_stats;
 
 /* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */
@@ -144,6 +147,7 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 /* Tuning knobs that do not change results. */
 #define GS_OPT_BLEND_THREADS 1   /* threads per tile in the blend (tile 16: 64/128/256; tile 32: 256/1024); 0 = default */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
+#define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
 /* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
 int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);
