@@ -3,7 +3,7 @@
 #include "gs_device.h"
 
 void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream_t st);
-void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, GsControl* ctl,
+void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                           hipStream_t st);
 uint32_t gs_scan_blocks(uint32_t n);
 void gs_launch_scan(const uint32_t* counts, uint32_t* offsets, uint32_t n, unsigned long long* status, GsControl* ctl,

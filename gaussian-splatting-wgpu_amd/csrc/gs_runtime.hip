@@ -261,7 +261,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
-    gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, c->ctl, st);
+    gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, st);
     mark(c, 1);
     gs_launch_scan(c->counts, c->offsets, c->n, c->scan_status, c->ctl, nullptr, st);
     mark(c, 2);

@@ -47,11 +47,15 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? counts[base + j] : 0u;
     }
-    uint32_t tsum = 0;
+    uint32_t tsum = 0, nz = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) tsum += v[j];
+    for (int j = 0; j < SCAN_ITEMS; ++j) { tsum += v[j]; nz += (v[j] != 0u); }
     const uint32_t incl = wave_incl_scan(tsum, lane);
     if (lane == 63) s_wsum[w] = incl;
+    // visible-gaussian statistic: one atomic per wave of 1024 gaussians (a single hot word serialises
+    // at ~88 atomics/us on this chip, so never one per 64 gaussians)
+    nz = wave_sum(nz);
+    if (lane == 0 && nz) atomicAdd(&ctl->num_visible, nz);
     __syncthreads();
     uint32_t wave_excl = 0, block_total = 0;
 #pragma unroll

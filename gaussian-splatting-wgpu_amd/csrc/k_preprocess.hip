@@ -80,7 +80,7 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
 }
 
 __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
-                                                             uint32_t* __restrict__ tile_counts, GsControl* ctl) {
+                                                             uint32_t* __restrict__ tile_counts) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t count = 0;
     if (i < f.n) {
@@ -203,9 +203,6 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniform
         }
         tile_counts[i] = count;
     }
-    // visible-gaussian statistic: one atomic per wave
-    const unsigned long long vis = __ballot(count > 0);
-    if (lane_id() == 0 && vis) atomicAdd(&ctl->num_visible, (uint32_t)__popcll(vis));
 }
 
 // ---- host launchers --------------------------------------------------------------------------------
@@ -216,9 +213,9 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
     hipLaunchKernelGGL(gs_repack_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)d_aos, n, (float*)s.px, (float*)s.py,
                        (float*)s.pz, (float*)s.sx, (float*)s.sy, (float*)s.sz, (float4*)s.rot, (float*)s.opac, (float4*)s.sh);
 }
-void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, GsControl* ctl,
+void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                           hipStream_t st) {
     const uint32_t blocks = (f.n + 255) / 256;
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_preprocess_kernel, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, ctl);
+    hipLaunchKernelGGL(gs_preprocess_kernel, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts);
 }
