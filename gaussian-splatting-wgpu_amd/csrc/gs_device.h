@@ -31,7 +31,7 @@ struct GsControl {
     uint32_t num_intersections; // I (written by the scan's last block)
     uint32_t num_visible;
     uint32_t pad0;
-    unsigned long long num_processed; // blend: staged list entries
+    unsigned long long num_processed[64]; // blend: staged list entries (64 partial sums)
     uint32_t hist[4][256];    // digit histograms -> exclusive digit bases
 };
 

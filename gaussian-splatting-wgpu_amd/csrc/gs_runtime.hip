@@ -404,7 +404,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
     if (c->have_frame) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
-        out->num_processed = c->h_ctl->num_processed;
+        for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
         if (c->have_events && c->frames > 0) {
             const uint64_t last = c->frames - 1;
             uint64_t first = c->timed_from;

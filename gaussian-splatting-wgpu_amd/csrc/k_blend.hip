@@ -6,10 +6,11 @@
 //
 // The reference re-gathers the 64-byte GaussianData record from global memory for every pixel of
 // the tile (256x redundant, compute_tiles.wgsl:49-50; README TODO "Load Gaussian data workgroup
-// wide").  Here a workgroup stages a batch of its tile's sorted list ONCE into LDS (36 B/entry:
-// centre in pixels, conic, opacity, colour), all pixels read the batch by LDS broadcast, and the
-// tile stops as soon as every pixel is finished under the exact criterion below -- which changes
-// no output bit:
+// wide").  Here a workgroup stages a batch of its tile's sorted list ONCE into LDS (40 B/entry:
+// centre in pixels, conic, opacity, colour, cull limit), each wave skips the entries that cannot
+// touch its 8x8 pixel block, pixels read the surviving entries by LDS broadcast, and the tile stops
+// as soon as every pixel is finished under the exact criterion below -- which changes no output
+// bit:
 //     a later entry can only be kept if alpha >= c (c = f32(1/255)) and T*(1-alpha) >= 1e-4;
 //     fl(T*fl(1-alpha)) <= fl(T*fl(1-c)) for every alpha >= c, so once fl(T*fl(1-c)) < 1e-4 the
 //     pixel's colour is final.
@@ -23,44 +24,67 @@
 // algorithmic bytes are 40 B per staged entry + 4 B per pixel.
 #include "gs_device.h"
 
-template <int TS, int NT, bool EXACT>
-__global__ __launch_bounds__(NT) void gs_blend_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
-                                                       const uint32_t* __restrict__ ranges, GsFrame f,
-                                                       uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl) {
-    constexpr int PPT = (TS * TS) / NT; // pixels per thread
-    static_assert(PPT * NT == TS * TS, "tile must divide evenly over the threads");
-    __shared__ float4 sA[NT]; // gx, gy, conic.x, conic.y   (fast mode: conic pre-scaled, see below)
-    __shared__ float4 sB[NT]; // conic.z, opacity, r, g
-    __shared__ float sC[NT];  // b
+// Minimum over the pixel block [dxlo,dxhi] x [dylo,dyhi] (offsets g - p) of the quadratic
+// q(d) = 0.5*(cx*dx^2 + cz*dy^2) + cy*dx*dy (power = -q).  For a positive-definite conic whose centre
+// is outside the block the minimiser lies on an edge facing the centre: at most two 1-D problems.
+__device__ __forceinline__ float block_qmin(float cx, float cy, float cz, float dxlo, float dxhi, float dylo, float dyhi,
+                                            float& mag) {
+    const float X = __builtin_fminf(__builtin_fmaxf(0.0f, dxlo), dxhi); // clamp(0, lo, hi)
+    const float Y = __builtin_fminf(__builtin_fmaxf(0.0f, dylo), dyhi);
+    float q = 3.0e38f;
+    mag = 0.0f;
+    if (X == 0.0f && Y == 0.0f) return 0.0f; // centre inside the block
+    if (X != 0.0f) {
+        const float dy = __builtin_fminf(__builtin_fmaxf(-cy * X / cz, dylo), dyhi);
+        const float a = 0.5f * cx * X * X, b = 0.5f * cz * dy * dy, c = cy * X * dy;
+        q = a + b + c;
+        mag = __builtin_fabsf(a) + __builtin_fabsf(b) + __builtin_fabsf(c);
+    }
+    if (Y != 0.0f) {
+        const float dx = __builtin_fminf(__builtin_fmaxf(-cy * Y / cx, dxlo), dxhi);
+        const float a = 0.5f * cx * dx * dx, b = 0.5f * cz * Y * Y, c = cy * dx * Y;
+        const float q2 = a + b + c;
+        if (q2 < q) { q = q2; mag = __builtin_fabsf(a) + __builtin_fabsf(b) + __builtin_fabsf(c); }
+    }
+    return q;
+}
 
-    const uint32_t tid = threadIdx.x;
+// One workgroup per tile, TS*TS threads, one pixel per thread; wave w owns the 8x8 pixel block
+// (w % (TS/8), w / (TS/8)) of the tile.  Per batch of NT staged entries every wave first builds,
+// 64 entries at a time (one per lane), the mask of entries that can reach alpha >= 1/255 somewhere
+// in ITS 8x8 block (conservative: an entry is dropped only if op*exp(-qmin) < c255 with a margin far
+// above f32 rounding, so no output bit changes), then walks only the set bits.
+template <int TS, bool EXACT>
+__global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
+                                                           const uint32_t* __restrict__ ranges, GsFrame f,
+                                                           uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl) {
+    constexpr int NT = TS * TS;
+    constexpr int ROUNDS = NT / 64; // 64-entry groups per batch
+    constexpr int WPR = TS / 8;     // waves per tile row
+    __shared__ float4 sA[NT]; // gx, gy, conic.x, conic.y        (fused mode: conic pre-scaled)
+    __shared__ float4 sB[NT]; // conic.z, opacity, r, g
+    __shared__ float2 sC[NT]; // b, ln(255*opacity) + margin
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t tx = f.col0 + blockIdx.x, ty = blockIdx.y;
     const uint32_t tile = tx + ty * f.ntx;
     const uint32_t start = tile > 0 ? ranges[tile - 1] : 0u;
     uint32_t end = ranges[tile];
     if (end > f.capacity) end = f.capacity;
 
-    float pxf[PPT], pyf[PPT], T[PPT], cr[PPT], cg[PPT], cb[PPT];
-    bool done[PPT];
-    bool all_done = true;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const uint32_t p = tid + k * NT;
-        const uint32_t gx = tx * TS + (p % TS), gy = ty * TS + (p / TS);
-        pxf[k] = (float)gx;
-        pyf[k] = (float)gy;
-        T[k] = 1.0f;
-        cr[k] = cg[k] = cb[k] = 0.0f;
-        done[k] = !(gx < f.width && gy < f.height);
-        all_done = all_done && done[k];
-    }
+    const uint32_t bx0 = tx * TS + (w % WPR) * 8, by0 = ty * TS + (w / WPR) * 8;
+    const uint32_t gx = bx0 + (lane & 7), gy = by0 + (lane >> 3);
+    const float pxf = (float)gx, pyf = (float)gy;
+    const float bx0f = (float)bx0, by0f = (float)by0;
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    bool done = !(gx < f.width && gy < f.height);
     const float c255 = (float)(1.0 / 255.0);
     const float Wf = (float)f.width, Hf = (float)f.height;
     uint32_t staged = 0;
 
     for (uint32_t b = start; b < end; b += NT) {
-        // barrier: the previous batch is no longer being read; stop when every pixel is final
-        if (__syncthreads_and(all_done ? 1 : 0)) break;
+        // barrier: the previous batch is no longer being read; stop when every pixel of the tile is final
+        if (__syncthreads_and(done ? 1 : 0)) break;
         const uint32_t idx = b + tid;
         if (idx < end) {
             const uint32_t g = values[idx];
@@ -68,86 +92,104 @@ __global__ __launch_bounds__(NT) void gs_blend_kernel(const uint4* __restrict__ 
             const uint4 r1 = gdata[(uint64_t)g * 4 + 1];
             const uint4 r2 = gdata[(uint64_t)g * 4 + 2];
             const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
+            const float op = __uint_as_float(r2.w);
             float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
             if (!EXACT) {
-                // fold -0.5 and log2(e) into the conic once per entry: power*log2e = hx*dx*dx + hz*dy*dy + hy*dx*dy
+                // fused mode: fold -0.5 and log2(e) into the conic once per entry, so that
+                // power*log2(e) = hx*dx^2 + hy*dx*dy + hz*dy^2
                 const float L = 1.44269502162933349609375f;
                 cx = (-0.5f * L) * cx;
-                cz = (-0.5f * L) * cz;
                 cy = (-L) * cy;
+                cz = (-0.5f * L) * cz;
             }
             sA[tid] = make_float4(gxp, gyp, cx, cy);
-            sB[tid] = make_float4(cz, __uint_as_float(r2.w), __uint_as_float(r2.x), __uint_as_float(r2.y));
-            sC[tid] = __uint_as_float(r2.z);
+            sB[tid] = make_float4(cz, op, __uint_as_float(r2.x), __uint_as_float(r2.y));
+            // alpha >= c255  <=>  q <= ln(255*op); +0.01 keeps the cull conservative (rounding is ~1e-6)
+            sC[tid] = make_float2(__uint_as_float(r2.z), __builtin_logf(op * 255.0f) + 0.01f);
         }
         __syncthreads();
         const uint32_t cnt = (end - b < (uint32_t)NT) ? end - b : (uint32_t)NT;
         staged += cnt;
-        if (!all_done) {
-            for (uint32_t e = 0; e < cnt; ++e) {
+        if (__ballot(!done) == 0ull) continue; // this wave's block is final (uniform per wave)
+
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e0 = (uint32_t)r * 64u;
+            if (e0 >= cnt) break;
+            bool rel = false;
+            if (e0 + lane < cnt) {
+                float4 a4 = sA[e0 + lane];
+                float cz = sB[e0 + lane].x;
+                const float lim = sC[e0 + lane].y;
+                if (!EXACT) { // undo the staging scale (the margin absorbs the extra rounding)
+                    const float iL = 0.693147182464599609375f;
+                    a4.z *= -2.0f * iL;
+                    a4.w *= -iL;
+                    cz *= -2.0f * iL;
+                }
+                const float dxhi = a4.x - bx0f, dxlo = dxhi - 7.0f, dyhi = a4.y - by0f, dylo = dyhi - 7.0f;
+                const bool pd = (a4.z > 0.0f) && (cz > 0.0f) && (a4.z * cz - a4.w * a4.w > 0.0f);
+                float mag;
+                const float q = block_qmin(a4.z, a4.w, cz, dxlo, dxhi, dylo, dyhi, mag);
+                rel = !pd || !(q > lim + 1.0e-5f * mag); // NaNs compare false -> relevant
+            }
+            unsigned long long m = __ballot(rel);
+            while (m) {
+                const uint32_t e = e0 + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
                 const float4 a4 = sA[e];
                 const float4 b4 = sB[e];
-                const float colb = sC[e];
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    if (done[k]) continue;
-                    const float dx = a4.x - pxf[k], dy = a4.y - pyf[k];
-                    if (EXACT) {
-                        const float t1 = a4.z * dx * dx, t2 = b4.x * dy * dy, t3 = a4.w * dx * dy;
-                        const float power = -0.5f * (t1 + t2) - t3;
-                        const float alpha = wg_min(0.99f, b4.y * gs_exp(power));
-                        const float test = T[k] * (1.0f - alpha);
-                        const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
-                        cr[k] += cond * b4.z * alpha * T[k];
-                        cg[k] += cond * b4.w * alpha * T[k];
-                        cb[k] += cond * colb * alpha * T[k];
-                        T[k] = cond * test + (1.0f - cond) * T[k];
-                        if (T[k] * (1.0f - c255) < 0.0001f) done[k] = true;
-                    } else {
-                        const float u = __builtin_fmaf(a4.z, dx, a4.w * dy);
-                        const float v = (b4.x * dy) * dy;
-                        const float p2 = __builtin_fmaf(dx, u, v); // power * log2(e)
-                        const float alpha = __builtin_fminf(0.99f, b4.y * __builtin_amdgcn_exp2f(p2));
-                        const float test = __builtin_fmaf(-T[k], alpha, T[k]);
-                        if (p2 <= 0.0f && alpha >= c255 && test >= 0.0001f) {
-                            const float wgt = alpha * T[k];
-                            cr[k] = __builtin_fmaf(b4.z, wgt, cr[k]);
-                            cg[k] = __builtin_fmaf(b4.w, wgt, cg[k]);
-                            cb[k] = __builtin_fmaf(colb, wgt, cb[k]);
-                            T[k] = test;
-                            if (__builtin_fmaf(-test, c255, test) < 0.0001f) done[k] = true;
-                        }
+                const float colb = sC[e].x;
+                if (done) continue;
+                const float dx = a4.x - pxf, dy = a4.y - pyf;
+                if (EXACT) {
+                    const float t1 = a4.z * dx * dx, t2 = b4.x * dy * dy, t3 = a4.w * dx * dy;
+                    const float power = -0.5f * (t1 + t2) - t3;
+                    const float alpha = wg_min(0.99f, b4.y * gs_exp(power));
+                    const float test = T * (1.0f - alpha);
+                    const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
+                    cr += cond * b4.z * alpha * T;
+                    cg += cond * b4.w * alpha * T;
+                    cb += cond * colb * alpha * T;
+                    T = cond * test + (1.0f - cond) * T;
+                    if (T * (1.0f - c255) < 0.0001f) done = true;
+                } else {
+                    const float u = __builtin_fmaf(a4.z, dx, a4.w * dy);
+                    const float v = (b4.x * dy) * dy;
+                    const float p2 = __builtin_fmaf(dx, u, v);
+                    const float alpha = __builtin_fminf(0.99f, b4.y * __builtin_amdgcn_exp2f(p2));
+                    const float test = __builtin_fmaf(-T, alpha, T);
+                    if (p2 <= 0.0f && alpha >= c255 && test >= 0.0001f) {
+                        const float wgt = alpha * T;
+                        cr = __builtin_fmaf(b4.z, wgt, cr);
+                        cg = __builtin_fmaf(b4.w, wgt, cg);
+                        cb = __builtin_fmaf(colb, wgt, cb);
+                        T = test;
+                        if (__builtin_fmaf(-test, c255, test) < 0.0001f) done = true;
                     }
                 }
             }
-            all_done = true;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
         }
     }
-    if (tid == 0 && staged) atomicAdd(&ctl->num_processed, (unsigned long long)staged);
+    // statistic: spread over 64 words so that 8 160+ tiles do not serialise on one atomic
+    if (tid == 0 && staged) atomicAdd(&ctl->num_processed[(blockIdx.x + blockIdx.y * gridDim.x) & 63u], (unsigned long long)staged);
 
     // textureStore(render_target, xy, vec4(C, 1)) to rgba8unorm (compute_tiles.wgsl:71): clamp, *255, round
+    if (gx < f.width && gy < f.height) {
+        const float c[3] = {cr, cg, cb};
+        uint32_t q = 0xFF000000u;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const uint32_t p = tid + k * NT;
-        const uint32_t gx = tx * TS + (p % TS), gy = ty * TS + (p / TS);
-        if (gx < f.width && gy < f.height) {
-            const float c[3] = {cr[k], cg[k], cb[k]};
-            uint32_t q = 0xFF000000u;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float v = c[ch];
-                v = (v != v) ? 0.0f : wg_min(wg_max(v, 0.0f), 1.0f);
-                q |= (uint32_t)__builtin_floorf(v * 255.0f + 0.5f) << (8 * ch);
-            }
-            const uint64_t o = (uint64_t)gy * f.slab_w + (gx - f.px0);
-            rgba8[o] = q;
-            if (rgbf) {
-                rgbf[o * 3 + 0] = cr[k];
-                rgbf[o * 3 + 1] = cg[k];
-                rgbf[o * 3 + 2] = cb[k];
-            }
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = c[ch];
+            v = (v != v) ? 0.0f : wg_min(wg_max(v, 0.0f), 1.0f);
+            q |= (uint32_t)__builtin_floorf(v * 255.0f + 0.5f) << (8 * ch);
+        }
+        const uint64_t o = (uint64_t)gy * f.slab_w + (gx - f.px0);
+        rgba8[o] = q;
+        if (rgbf) {
+            rgbf[o * 3 + 0] = cr;
+            rgbf[o * 3 + 1] = cg;
+            rgbf[o * 3 + 2] = cb;
         }
     }
 }
@@ -168,31 +210,24 @@ __global__ __launch_bounds__(256) void gs_assemble_kernel(const uint32_t* __rest
 }
 
 // ---- host launchers --------------------------------------------------------------------------------
-template <int TS, int NT>
+template <int TS>
 static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* gdata, const uint32_t* values, const uint32_t* ranges,
                            const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl) {
     if (exact)
-        hipLaunchKernelGGL((gs_blend_kernel<TS, NT, true>), grid, dim3(NT), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl);
+        hipLaunchKernelGGL((gs_blend_kernel<TS, true>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl);
     else
-        hipLaunchKernelGGL((gs_blend_kernel<TS, NT, false>), grid, dim3(NT), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl);
+        hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl);
 }
-// threads_per_tile: 0 = default for the tile size.
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
                     GsControl* ctl, bool exact, uint32_t threads_per_tile, hipStream_t st) {
+    (void)threads_per_tile;
     const dim3 grid(f.col1 - f.col0, f.nty);
     if (grid.x == 0 || grid.y == 0) return 0;
     const uint4* g = (const uint4*)gdata;
     switch (f.tile_size) {
-    case 8: launch_blend_t<8, 64>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
-    case 16:
-        if (threads_per_tile == 64) launch_blend_t<16, 64>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl);
-        else if (threads_per_tile == 128) launch_blend_t<16, 128>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl);
-        else launch_blend_t<16, 256>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl);
-        return 0;
-    case 32:
-        if (threads_per_tile == 1024) launch_blend_t<32, 1024>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl);
-        else launch_blend_t<32, 256>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl);
-        return 0;
+    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
+    case 16: launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
+    case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
     default: return -1;
     }
 }

@@ -81,20 +81,6 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
-@pytest.mark.parametrize("threads", [64, 128, 256])
-def test_blend_thread_shapes(oracle, threads):
-    from gsplat import _abi
-    n, W, H = 30000, 384, 256
-    s, u = scene(n), _uniforms(W, H, step=7)
-    ref = oracle.render(s, u, W, H, 16)
-    r = _mk(s, W, H, 16, flags=_abi.GS_FLAG_EXACT_BLEND)
-    r.set_option(_abi.GS_OPT_BLEND_THREADS, threads)
-    r.render_uniforms(u, debug=True)
-    r.wait()
-    _check_stages(r, ref, exact_image=True)
-    r.destroy()
-
-
 def test_sort_kat_reference_testsort():
     """radix_sort/utils.ts:55-81: 8192 keys n-1-i must come out 0..n-1."""
     from gsplat import _abi
