@@ -181,7 +181,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
                        "parallelism": "tile-column slabs x%d + all-gather" % world if world > 1 else "single GPU",
-                       "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip,
+                       "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
                        "sort_passes": st["sort_passes"], "camera": "64-step orbit, moved every frame"},
         }
         if not args.no_timing and st["frames_timed"]:

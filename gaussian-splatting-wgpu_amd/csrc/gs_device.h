@@ -32,6 +32,7 @@ struct GsControl {
     uint32_t num_visible;
     uint32_t pad0;
     unsigned long long num_processed[64]; // blend: staged list entries (64 partial sums)
+    unsigned long long num_evaluated[64]; // blend: (wave, entry) pairs that survived the 8x8 cull
     uint32_t hist[4][256];    // digit histograms -> exclusive digit bases
 };
 

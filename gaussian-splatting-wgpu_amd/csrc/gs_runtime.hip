@@ -405,6 +405,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
+        for (int k = 0; k < 64; ++k) out->num_evaluated += c->h_ctl->num_evaluated[k];
         if (c->have_events && c->frames > 0) {
             const uint64_t last = c->frames - 1;
             uint64_t first = c->timed_from;

@@ -14,7 +14,9 @@
 #include "gs_device.h"
 
 // ------------------------------------------------------------------------------------------------
-// Exclusive scan, 4096 counts per workgroup, status granule = {flag:2, value:62} in one 8-byte word.
+// Exclusive scan, 4096 counts per workgroup, status granule = {flag:2, visible:30, sum:32} in one 8-byte
+// word: the count of visible gaussians rides along the same look-back (a separate atomic counter on one
+// hot word serialises at ~88 atomics/us on this chip).
 // ------------------------------------------------------------------------------------------------
 #define SCAN_ITEMS 16
 #define SCAN_TILE (256 * SCAN_ITEMS)
@@ -27,6 +29,7 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
                                                        uint32_t* total_out) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wnz[4];
     __shared__ uint32_t s_prefix;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_bid = atomicAdd(&ctl->scan_ticket, 1u);
@@ -52,23 +55,23 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
     for (int j = 0; j < SCAN_ITEMS; ++j) { tsum += v[j]; nz += (v[j] != 0u); }
     const uint32_t incl = wave_incl_scan(tsum, lane);
     if (lane == 63) s_wsum[w] = incl;
-    // visible-gaussian statistic: one atomic per wave of 1024 gaussians (a single hot word serialises
-    // at ~88 atomics/us on this chip, so never one per 64 gaussians)
     nz = wave_sum(nz);
-    if (lane == 0 && nz) atomicAdd(&ctl->num_visible, nz);
+    if (lane == 0) s_wnz[w] = nz;
     __syncthreads();
-    uint32_t wave_excl = 0, block_total = 0;
+    uint32_t wave_excl = 0, block_total = 0, block_nz = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t t = s_wsum[k];
         if (k < (int)w) wave_excl += t;
         block_total += t;
+        block_nz += s_wnz[k];
     }
     uint32_t run = wave_excl + incl - tsum;
 
     if (w == 0) {
-        if (lane == 0) st_agent64(&status[bid], (bid == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long)block_total);
-        uint32_t excl = 0;
+        const unsigned long long mine = ((unsigned long long)block_nz << 32) | (unsigned long long)block_total;
+        if (lane == 0) st_agent64(&status[bid], (bid == 0 ? ST_PREFIX : ST_AGG) | mine);
+        uint32_t excl = 0, excl_nz = 0;
         if (bid > 0) {
             int look = (int)bid - 1;
             for (;;) {
@@ -88,16 +91,20 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
                 }
                 const unsigned long long pmask = __ballot((sv & ST_MASK) == ST_PREFIX);
                 const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-                const uint32_t contrib = (lane <= first) ? (uint32_t)(sv & ~ST_MASK) : 0u;
+                const uint32_t contrib = (lane <= first) ? (uint32_t)sv : 0u;
+                const uint32_t contrib_nz = (lane <= first) ? (uint32_t)((sv & ~ST_MASK) >> 32) : 0u;
                 excl += wave_sum(contrib);
+                excl_nz += wave_sum(contrib_nz);
                 if (pmask) break;
                 look -= 64;
             }
         }
         if (lane == 0) {
-            if (bid > 0) st_agent64(&status[bid], ST_PREFIX | (unsigned long long)(excl + block_total));
+            if (bid > 0)
+                st_agent64(&status[bid], ST_PREFIX | ((unsigned long long)(excl_nz + block_nz) << 32) | (unsigned long long)(excl + block_total));
             s_prefix = excl;
             if (bid == nblocks - 1) {
+                ctl->num_visible = excl_nz + block_nz;
                 ctl->num_intersections = excl + block_total;
                 if (total_out) *total_out = excl + block_total;
             }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
     bool done = !(gx < f.width && gy < f.height);
     const float c255 = (float)(1.0 / 255.0);
     const float Wf = (float)f.width, Hf = (float)f.height;
-    uint32_t staged = 0;
+    uint32_t staged = 0, evaluated = 0;
 
     for (uint32_t b = start; b < end; b += NT) {
         // barrier: the previous batch is no longer being read; stop when every pixel of the tile is final
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
                 rel = !pd || !(q > lim + 1.0e-5f * mag); // NaNs compare false -> relevant
             }
             unsigned long long m = __ballot(rel);
+            evaluated += (uint32_t)__popcll(m);
             while (m) {
                 const uint32_t e = e0 + (uint32_t)__builtin_ctzll(m);
                 m &= m - 1ull;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
     }
     // statistic: spread over 64 words so that 8 160+ tiles do not serialise on one atomic
     if (tid == 0 && staged) atomicAdd(&ctl->num_processed[(blockIdx.x + blockIdx.y * gridDim.x) & 63u], (unsigned long long)staged);
+    if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(blockIdx.x + blockIdx.y * gridDim.x + w) & 63u], (unsigned long long)evaluated);
 
     // textureStore(render_target, xy, vec4(C, 1)) to rgba8unorm (compute_tiles.wgsl:71): clamp, *255, round
     if (gx < f.width && gy < f.height) {

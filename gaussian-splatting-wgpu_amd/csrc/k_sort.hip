@@ -65,128 +65,143 @@ __global__ __launch_bounds__(256) void gs_sort_hist_scan_kernel(GsControl* ctl, 
 }
 
 // ---- one digit sweep ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gs_sort_sweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+struct SweepShared {
+    uint32_t hist[4][256];  // per-wave digit counts -> exclusive offsets across waves -> + digit start
+    uint32_t gbase[256];    // global address of slot 0 of each digit's run, minus the digit's first slot
+    uint32_t keys[RS_TILE];
+    uint32_t vals[RS_TILE];
+    uint32_t wsum[4];
+    uint32_t tile;
+};
+
+template <bool FULL>
+__device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, GsControl* ctl,
+                                           uint32_t pass, uint32_t* status, uint32_t tile, uint32_t valid) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t shift = pass * 8;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t wbase = w * (64 * RS_ITEMS) + lane; // this lane's first slot in the tile
+    const uint32_t* kp = keys_in + (uint64_t)tile * RS_TILE + wbase;
+    const uint32_t* vp = vals_in + (uint64_t)tile * RS_TILE + wbase;
+
+    uint32_t key[RS_ITEMS];
+    uint32_t rank2[RS_ITEMS / 2]; // two 16-bit in-wave ranks per register
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        if (FULL) key[j] = kp[j * 64];
+        else key[j] = (wbase + j * 64 < valid) ? kp[j * 64] : 0xFFFFFFFFu; // pads sort last and are never stored
+    }
+    for (uint32_t k = lane; k < 256; k += 64) sh.hist[w][k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // rank inside the wave: peers = lanes holding the same digit (8 ballots), order = (item, lane)
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const uint32_t d = (key[j] >> shift) & 255u;
+        uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint32_t bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit != 0u);
+            const uint32_t inv = bit - 1u; // 0 when the bit is set, ~0 when clear: peers &= bit ? bal : ~bal
+            plo &= (uint32_t)bal ^ inv;
+            phi &= (uint32_t)(bal >> 32) ^ inv;
+        }
+        const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
+        const uint32_t cnt = __popc(plo) + __popc(phi);
+        const uint32_t pre = sh.hist[w][d];
+        // every peer has read `pre` before the leader's store is issued: one wave, in-order LDS
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (below == 0) sh.hist[w][d] = pre + cnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t r = pre + below; // < 1024
+        if (j & 1) rank2[j >> 1] |= r << 16;
+        else rank2[j >> 1] = r;
+    }
+    __syncthreads();
+
+    // thread d: counts of digit d per wave -> exclusive offsets across waves, tile total
+    const uint32_t c0 = sh.hist[0][tid], c1 = sh.hist[1][tid], c2 = sh.hist[2][tid], c3 = sh.hist[3][tid];
+    const uint32_t total = c0 + c1 + c2 + c3;
+    const uint32_t incl = wave_incl_scan(total, lane);
+    if (lane == 63) sh.wsum[w] = incl;
+
+    // publish this tile's digit count, then walk back over the predecessors' words
+    uint32_t* my = status + (uint64_t)tile * 256 + tid;
+    uint32_t excl = 0;
+    if (tile == 0) {
+        st_agent(my, RS_PREFIX | total);
+    } else {
+        st_agent(my, RS_AGG | total);
+        for (int t = (int)tile - 1; t >= 0; --t) {
+            const uint32_t* p = status + (uint64_t)t * 256 + tid;
+            uint32_t sv, spins = 0;
+            do {
+                sv = ld_agent(p);
+                if (sv & RS_FLAGS) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < GS_SPIN_LIMIT);
+            if ((sv & RS_FLAGS) == 0) { ctl->fault = 1u; break; }
+            excl += sv & RS_VALUE;
+            if ((sv & RS_FLAGS) == RS_PREFIX) break;
+        }
+        st_agent(my, RS_PREFIX | ((excl + total) & RS_VALUE));
+    }
+    __syncthreads();
+    uint32_t wv = 0;
+    for (uint32_t k = 0; k < w; ++k) wv += sh.wsum[k];
+    const uint32_t dstart = wv + incl - total; // first slot of digit `tid` in the tile's sorted order
+    sh.hist[0][tid] = dstart;
+    sh.hist[1][tid] = dstart + c0;
+    sh.hist[2][tid] = dstart + c0 + c1;
+    sh.hist[3][tid] = dstart + c0 + c1 + c2;
+    sh.gbase[tid] = ctl->hist[pass][tid] + excl - dstart;
+    __syncthreads();
+
+    // reorder through LDS, then store each digit's run contiguously (payloads are only loaded now:
+    // holding them across the ranking phase costs 16 VGPRs and a wave of occupancy)
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        uint32_t v;
+        if (FULL) v = vp[j * 64];
+        else v = (wbase + j * 64 < valid) ? vp[j * 64] : 0u;
+        const uint32_t d = (key[j] >> shift) & 255u;
+        const uint32_t r = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
+        const uint32_t pos = sh.hist[w][d] + r;
+        sh.keys[pos] = key[j];
+        sh.vals[pos] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const uint32_t pos = j * 256 + tid;
+        if (FULL || pos < valid) {
+            const uint32_t k = sh.keys[pos];
+            const uint32_t g = sh.gbase[(k >> shift) & 255u] + pos;
+            keys_out[g] = k;
+            vals_out[g] = sh.vals[pos];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void gs_sort_sweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              GsControl* ctl, const uint32_t* __restrict__ n_ptr, uint32_t capacity,
                                                              uint32_t pass, uint32_t* status) {
-    __shared__ uint32_t s_hist[4][256];  // per-wave digit counts, then exclusive offsets across waves
-    __shared__ uint32_t s_dstart[256];   // first slot of each digit in the tile's sorted order
-    __shared__ uint32_t s_gbase[256];    // global address of slot 0 of each digit's run, minus s_dstart
-    __shared__ uint32_t s_keys[RS_TILE];
-    __shared__ uint32_t s_vals[RS_TILE];
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_tile;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t shift = pass * 8;
+    __shared__ SweepShared sh;
     uint32_t n = *n_ptr;
     if (n > capacity) n = capacity;
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&ctl->sort_ticket[pass], 1u);
+        if (threadIdx.x == 0) sh.tile = atomicAdd(&ctl->sort_ticket[pass], 1u);
         __syncthreads();
-        const uint32_t tile = s_tile;
+        const uint32_t tile = sh.tile;
         if (tile >= ntiles) break; // uniform: every thread read the same ticket
-        const uint32_t tile_base = tile * RS_TILE;
-        const uint32_t valid = (n - tile_base < RS_TILE) ? n - tile_base : RS_TILE;
-
-        uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
-#pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) {
-            const uint32_t li = w * (64 * RS_ITEMS) + j * 64 + lane;
-            const bool ok = li < valid;
-            key[j] = ok ? keys_in[tile_base + li] : 0xFFFFFFFFu; // pads sort last and are never stored
-            val[j] = ok ? vals_in[tile_base + li] : 0u;
-        }
-        for (uint32_t k = lane; k < 256; k += 64) s_hist[w][k] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // rank inside the wave: peers = lanes holding the same digit (8 ballots), order = (item, lane)
-#pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) {
-            const uint32_t d = (key[j] >> shift) & 255u;
-            unsigned long long peers = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-            const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
-            const uint32_t cnt = (uint32_t)__popcll(peers);
-            const uint32_t pre = s_hist[w][d];
-            // every peer has read `pre` before the leader's store is issued: one wave, in-order LDS
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (below == 0) s_hist[w][d] = pre + cnt;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            rank[j] = pre + below;
-        }
-        __syncthreads();
-
-        // thread d: counts of digit d per wave -> exclusive offsets across waves, tile total
-        uint32_t total;
-        {
-            const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
-            s_hist[0][tid] = 0;
-            s_hist[1][tid] = c0;
-            s_hist[2][tid] = c0 + c1;
-            s_hist[3][tid] = c0 + c1 + c2;
-            total = c0 + c1 + c2 + c3;
-        }
-        const uint32_t incl = wave_incl_scan(total, lane);
-        if (lane == 63) s_wsum[w] = incl;
-
-        // publish this tile's digit count, then walk back over the predecessors' words
-        uint32_t* my = status + (uint64_t)tile * 256 + tid;
-        uint32_t excl = 0;
-        if (tile == 0) {
-            st_agent(my, RS_PREFIX | total);
-        } else {
-            st_agent(my, RS_AGG | total);
-            for (int t = (int)tile - 1; t >= 0; --t) {
-                const uint32_t* p = status + (uint64_t)t * 256 + tid;
-                uint32_t sv, spins = 0;
-                do {
-                    sv = ld_agent(p);
-                    if (sv & RS_FLAGS) break;
-                    __builtin_amdgcn_s_sleep(1);
-                } while (++spins < GS_SPIN_LIMIT);
-                if ((sv & RS_FLAGS) == 0) { ctl->fault = 1u; break; }
-                excl += sv & RS_VALUE;
-                if ((sv & RS_FLAGS) == RS_PREFIX) break;
-            }
-            st_agent(my, RS_PREFIX | ((excl + total) & RS_VALUE));
-        }
-        __syncthreads();
-        uint32_t wbase = 0;
-        for (uint32_t k = 0; k < w; ++k) wbase += s_wsum[k];
-        const uint32_t dstart = wbase + incl - total;
-        s_dstart[tid] = dstart;
-        s_gbase[tid] = ctl->hist[pass][tid] + excl - dstart;
-        __syncthreads();
-
-        // reorder through LDS, then store each digit's run contiguously
-#pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) {
-            const uint32_t d = (key[j] >> shift) & 255u;
-            const uint32_t pos = s_dstart[d] + s_hist[w][d] + rank[j];
-            s_keys[pos] = key[j];
-            s_vals[pos] = val[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) {
-            const uint32_t pos = j * 256 + tid;
-            if (pos < valid) {
-                const uint32_t k = s_keys[pos];
-                const uint32_t g = s_gbase[(k >> shift) & 255u] + pos;
-                keys_out[g] = k;
-                vals_out[g] = s_vals[pos];
-            }
-        }
+        const uint32_t valid = (n - tile * RS_TILE < RS_TILE) ? n - tile * RS_TILE : RS_TILE;
+        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, pass, status, tile, valid);
+        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, pass, status, tile, valid);
         __syncthreads(); // LDS is reused by the next tile
     }
 }

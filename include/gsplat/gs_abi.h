@@ -90,6 +90,8 @@ typedef struct gs_stats {
     float stage_us_mean[GS_STAGE_COUNT]; /* mean over the frames since GS_OPT_RESET_TIMING (at most the last 256) */
     float frame_us_mean;
     uint32_t frames_timed;        /* frames the means cover                                    */
+    uint32_t pad_;
+    uint64_t num_evaluated;       /* blend: (8x8 pixel block, entry) pairs evaluated after the block cull */
 } gs_stats;
 
 /* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */
