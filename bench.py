@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--n", type=int, default=0, help="override the gaussian count")
     ap.add_argument("--tile", type=int, default=16)
-    ap.add_argument("--blend-threads", type=int, default=0)
+    ap.add_argument("--blend-ablation", type=int, default=0, help="profiling only: see GS_OPT_BLEND_ABLATION")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -123,8 +123,8 @@ def main():
                         stream=stream)
     del splats, pg
     torch.cuda.empty_cache()
-    if args.blend_threads:
-        r.set_option(_abi.GS_OPT_BLEND_THREADS, args.blend_threads)
+    if args.blend_ablation:
+        r.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
     slab_w_max = max(min(W, bounds[g + 1] * ts) - bounds[g] * ts for g in range(world))

@@ -46,7 +46,7 @@ struct gs_ctx {
     GsFrame frame{};
     uint32_t T = 0, passes = 0, key_bits = 0;
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
-    uint32_t blend_threads = 0;
+    uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
     // scene planes
     void* scene_mem = nullptr;
     GsScene scene{};
@@ -282,7 +282,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
     if (gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
-                        c->blend_threads, st) != 0)
+                        c->blend_ablation, st) != 0)
         return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
     mark(c, 6);
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
@@ -445,7 +445,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
 GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: null ctx");
     switch (key) {
-    case GS_OPT_BLEND_THREADS: c->blend_threads = (uint32_t)value; return GS_OK;
+    case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; return GS_OK;
     default: break;

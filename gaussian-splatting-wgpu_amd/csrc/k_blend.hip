@@ -57,7 +57,7 @@ __device__ __forceinline__ float block_qmin(float cx, float cy, float cz, float 
 template <int TS, bool EXACT>
 __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                            const uint32_t* __restrict__ ranges, GsFrame f,
-                                                           uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl) {
+                                                           uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl, uint32_t dbg) {
     constexpr int NT = TS * TS;
     constexpr int ROUNDS = NT / 64; // 64-entry groups per batch
     constexpr int WPR = TS / 8;     // waves per tile row
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
         if (__syncthreads_and(done ? 1 : 0)) break;
         const uint32_t idx = b + tid;
         if (idx < end) {
-            const uint32_t g = values[idx];
+            uint32_t g = values[idx];
+            if (dbg & 2u) g = (g & 1023u); // TIMING EXPERIMENT ONLY: gather from a cache-resident window
             const uint4 r0 = gdata[(uint64_t)g * 4 + 0];
             const uint4 r1 = gdata[(uint64_t)g * 4 + 1];
             const uint4 r2 = gdata[(uint64_t)g * 4 + 2];
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
                 float mag;
                 const float q = block_qmin(a4.z, a4.w, cz, dxlo, dxhi, dylo, dyhi, mag);
                 rel = !pd || !(q > lim + 1.0e-5f * mag); // NaNs compare false -> relevant
+                if (dbg & 1u) rel = false; // TIMING EXPERIMENT ONLY: staging + cull cost without the pixel loop
             }
             unsigned long long m = __ballot(rel);
             evaluated += (uint32_t)__popcll(m);
@@ -214,22 +216,22 @@ __global__ __launch_bounds__(256) void gs_assemble_kernel(const uint32_t* __rest
 // ---- host launchers --------------------------------------------------------------------------------
 template <int TS>
 static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* gdata, const uint32_t* values, const uint32_t* ranges,
-                           const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl) {
+                           const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl, uint32_t dbg) {
     if (exact)
-        hipLaunchKernelGGL((gs_blend_kernel<TS, true>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl);
+        hipLaunchKernelGGL((gs_blend_kernel<TS, true>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg);
     else
-        hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl);
+        hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg);
 }
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, bool exact, uint32_t threads_per_tile, hipStream_t st) {
-    (void)threads_per_tile;
+                    GsControl* ctl, bool exact, uint32_t ablation, hipStream_t st) {
+    const uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
     const dim3 grid(f.col1 - f.col0, f.nty);
     if (grid.x == 0 || grid.y == 0) return 0;
     const uint4* g = (const uint4*)gdata;
     switch (f.tile_size) {
-    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
-    case 16: launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
-    case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl); return 0;
+    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
+    case 16: launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
+    case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
     default: return -1;
     }
 }

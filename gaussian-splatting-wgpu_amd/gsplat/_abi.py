@@ -19,7 +19,7 @@ GS_STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend")
 (GS_BUF_TILE_COUNTS, GS_BUF_TILE_OFFSETS, GS_BUF_GAUSSIAN_DATA, GS_BUF_KEYS_UNSORTED, GS_BUF_VALUES_UNSORTED, GS_BUF_KEYS,
  GS_BUF_VALUES, GS_BUF_RANGES, GS_BUF_RGBA8, GS_BUF_RGB_F32) = range(10)
 
-GS_OPT_BLEND_THREADS = 1
+GS_OPT_BLEND_ABLATION = 1
 GS_OPT_PERSISTENT_GRID = 2
 GS_OPT_RESET_TIMING = 3
 

@@ -146,8 +146,8 @@ int32_t gs_read_buffer(gs_ctx* ctx, int32_t which, void* dst, uint64_t size, uin
 /* Device address of a tap (valid until the next gs_render / gs_destroy), for zero-copy consumers. */
 int32_t gs_device_ptr(gs_ctx* ctx, int32_t which, void** d_ptr);
 int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
-/* Tuning knobs that do not change results. */
-#define GS_OPT_BLEND_THREADS 1   /* threads per tile in the blend (tile 16: 64/128/256; tile 32: 256/1024); 0 = default */
+/* Tuning / profiling knobs. */
+#define GS_OPT_BLEND_ABLATION 1  /* PROFILING ONLY, breaks the image: bit0 = skip the per-pixel loop, bit1 = gather from a cache-resident window */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
 #define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
