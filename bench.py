@@ -110,8 +110,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     seed = synth.BASE_SEED + {"A": 0, "B": 1, "C": 2, "E": 4}[args.config]
-    ntx = int(np.ceil(np.float32(W) / np.float32(ts)))
-    bounds = [ntx * g // world for g in range(world + 1)]  # tile-column slabs
+    from gsplat import multigpu
+    bounds = multigpu.slab_bounds(W, ts, world)  # tile-column slabs
     cols = (bounds[rank], bounds[rank + 1])
 
     splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
@@ -127,21 +127,19 @@ def main():
         r.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
-    slab_w_max = max(min(W, bounds[g + 1] * ts) - bounds[g] * ts for g in range(world))
+    xch = None
     if world > 1:
-        send = torch.zeros((H * slab_w_max * 4,), dtype=torch.uint8, device=dev)
-        gathered = torch.zeros((world * H * slab_w_max * 4,), dtype=torch.uint8, device=dev)
-        image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+        xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, renderer=r)
 
     def step(k):
         u = uniforms[k % 64]
         if world == 1:
             r.render_uniforms(u)
         else:
-            r.render_uniforms(u, out_ptr=send.data_ptr())
-            dist.all_gather_into_tensor(gathered, send)  # one RCCL gather of the slabs over xGMI
+            r.render_uniforms(u, out_ptr=xch.send.data_ptr())  # blend writes straight into the send buffer
+            xch.exchange()                                      # one RCCL all-gather of the slabs over xGMI
             if rank == 0:
-                r.assemble(gathered.data_ptr(), bounds, H * slab_w_max * 4, image.data_ptr())
+                xch.assemble()
 
     def sync():
         r.wait()

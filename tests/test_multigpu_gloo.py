@@ -1,0 +1,60 @@
+"""world_size-2/3 gloo runs of the N>1 data path on CPU: slab bounds, padded all-gather, assembly.
+The slabs themselves are rendered with the oracle here (no GPU); on GPUs the same SlabExchange
+carries the HIP renderer's output (bench.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, W, H, ts, out):
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-wgpu_amd"))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gsplat import multigpu, synth
+    from oracle import gs_oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gs_oracle.set_num_threads(2)
+    s = synth.bicycle_like(6000)
+    u = synth.orbit_camera(9, W, H).uniforms(W, H)
+    x = multigpu.SlabExchange(W, H, ts, world, rank, torch.device("cpu"))
+    r = gs_oracle.render(s, u, W, H, ts, cols=x.cols, want_f32=False)
+    b, e = x.pixels[rank]
+    slab = np.ascontiguousarray(r["rgba8"][:, b:e])
+    x.send[: slab.size] = torch.from_numpy(slab.reshape(-1))
+    x.exchange()
+    img = x.assemble().numpy()
+    tot = torch.tensor([r["num_intersections"]], dtype=torch.int64)
+    dist.all_reduce(tot)
+    if rank == 0:
+        full = gs_oracle.render(s, u, W, H, ts, want_f32=False)
+        np.save(out, np.array([int(np.array_equal(img, full["rgba8"])), int(tot.item() == full["num_intersections"])]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,ts", [(2, 320, 160, 16), (3, 200, 96, 8)])
+def test_slab_exchange_gloo(tmp_path, world, W, H, ts):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, W, H, ts, out), nprocs=world, join=True)
+    ok = np.load(out)
+    assert ok[0] == 1, "assembled frame differs from the single-device frame"
+    assert ok[1] == 1, "slab intersection counts do not add up"
+
+
+def test_slab_bounds():
+    from gsplat import multigpu
+    assert multigpu.slab_bounds(1920, 16, 8) == [0, 15, 30, 45, 60, 75, 90, 105, 120]
+    assert multigpu.slab_bounds(3840, 16, 8)[1] == 30
+    b = multigpu.slab_bounds(200, 16, 3)  # 13 columns
+    assert b[0] == 0 and b[-1] == 13 and all(x < y for x, y in zip(b, b[1:]))
+    assert multigpu.slab_pixels(b, 200, 16)[-1][1] == 200
+    with pytest.raises(ValueError):
+        multigpu.slab_bounds(64, 16, 5)
