@@ -51,3 +51,21 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+
+
+def build_napi(force=False, verbose=False):
+    """Plain-C N-API addon (no node-gyp): gcc against /usr/include/node, linked to libgsplat_hip.so
+    with an $ORIGIN rpath.  Skipped (returns None) when the node headers are not installed."""
+    inc = "/usr/include/node"
+    if not os.path.exists(os.path.join(inc, "node_api.h")):
+        return None
+    so = build(force=force, verbose=verbose)
+    src = os.path.join(HERE, "napi", "gs_napi.c")
+    out = os.path.join(OUT, "gsplat_napi.node")
+    if force or _stale(out, [src, so, os.path.join(HERE, "..", "..", "include", "gsplat", "gs_abi.h")]):
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-DNODE_GYP_MODULE_NAME=gsplat_napi", "-I" + inc, src, "-o", out,
+               "-L" + OUT, "-lgsplat_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return os.path.abspath(out)

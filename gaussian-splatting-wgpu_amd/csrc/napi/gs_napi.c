@@ -1,0 +1,336 @@
+/*
+ * gs_napi.c -- plain-C N-API shim over include/gsplat/gs_abi.h (NAPI v4+, Node >= 12).
+ *
+ * This is the binding a Node host uses to put the MI355X rasterizer behind the reference's
+ * TypeScript surface (Renderer / Camera / PackedGaussians, see ../../js).  It adds nothing to the
+ * C ABI: every export is a 1:1 wrapper; HIP errors become thrown JS Errors / rejected Promises.
+ * The per-frame call never blocks the JS thread: renderAsync() enqueues and waits in a libuv worker
+ * (napi_async_work) and resolves a Promise, which is what Renderer.animate() awaits where the
+ * reference awaits queue.onSubmittedWorkDone() (renderer.ts:404-587).
+ */
+#define NAPI_VERSION 4
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/gsplat/gs_abi.h"
+
+#define NAPI_CALL(env, call)                                              \
+    do {                                                                  \
+        napi_status s_ = (call);                                          \
+        if (s_ != napi_ok) {                                              \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);   \
+            return NULL;                                                  \
+        }                                                                 \
+    } while (0)
+
+static napi_value throw_gs(napi_env env, int32_t rc) {
+    char msg[640];
+    const char* e = gs_last_error();
+    strcpy(msg, "gsplat: ");
+    strncat(msg, e && e[0] ? e : "error", sizeof(msg) - 32);
+    char code[16];
+    int n = 0, v = rc < 0 ? -rc : rc;
+    code[n++] = '-';
+    if (v >= 10) code[n++] = (char)('0' + v / 10);
+    code[n++] = (char)('0' + v % 10);
+    code[n] = 0;
+    napi_throw_error(env, code, msg);
+    return NULL;
+}
+
+static int get_u32_prop(napi_env env, napi_value obj, const char* name, uint32_t* out) {
+    napi_value v;
+    bool has = false;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    double d;
+    if (napi_get_value_double(env, v, &d) != napi_ok) return 0;
+    *out = (uint32_t)d;
+    return 1;
+}
+
+static gs_ctx* unwrap(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "gsplat: expected a context handle");
+        return NULL;
+    }
+    return *(gs_ctx**)p; /* the external holds a box so destroy() can null it */
+}
+
+static void finalize_ctx(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    gs_ctx** box = (gs_ctx**)data;
+    if (*box) gs_destroy(*box);
+    free(box);
+}
+
+/* bytes of an ArrayBuffer or of any TypedArray/Buffer view */
+static int get_bytes(napi_env env, napi_value v, void** data, size_t* len) {
+    bool is = false;
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) return napi_get_arraybuffer_info(env, v, data, len) == napi_ok;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type t;
+        size_t n, off;
+        napi_value ab;
+        if (napi_get_typedarray_info(env, v, &t, &n, data, &ab, &off) != napi_ok) return 0;
+        static const size_t sz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        *len = n * sz[t];
+        return 1;
+    }
+    if (napi_is_buffer(env, v, &is) == napi_ok && is) return napi_get_buffer_info(env, v, data, len) == napi_ok;
+    return 0;
+}
+
+/* create({width,height,tileSize,device,colBegin,colEnd,flags,maxIntersections}) -> handle */
+static napi_value js_create(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.tile_size = 16;
+    uint32_t dev = 0, maxi = 0;
+    if (argc < 1 || !get_u32_prop(env, argv[0], "width", &cfg.width) || !get_u32_prop(env, argv[0], "height", &cfg.height)) {
+        napi_throw_type_error(env, NULL, "gsplat.create: {width, height} required");
+        return NULL;
+    }
+    get_u32_prop(env, argv[0], "tileSize", &cfg.tile_size);
+    if (get_u32_prop(env, argv[0], "device", &dev)) cfg.device = (int32_t)dev;
+    get_u32_prop(env, argv[0], "colBegin", &cfg.col_begin);
+    get_u32_prop(env, argv[0], "colEnd", &cfg.col_end);
+    get_u32_prop(env, argv[0], "flags", &cfg.flags);
+    if (get_u32_prop(env, argv[0], "maxIntersections", &maxi)) cfg.max_intersections = maxi;
+    gs_ctx* ctx = NULL;
+    int32_t rc = gs_create(&cfg, &ctx);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    gs_ctx** box = (gs_ctx**)malloc(sizeof(gs_ctx*));
+    *box = ctx;
+    napi_value ext;
+    NAPI_CALL(env, napi_create_external(env, box, finalize_ctx, NULL, &ext));
+    return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void* p = NULL;
+    if (argc < 1 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p) return NULL;
+    gs_ctx** box = (gs_ctx**)p;
+    if (*box) {
+        gs_destroy(*box);
+        *box = NULL;
+    }
+    return NULL;
+}
+
+/* uploadSplats(handle, bytes, n) */
+static napi_value js_upload(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 3 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    void* data = NULL;
+    size_t len = 0;
+    double n = 0;
+    if (!get_bytes(env, argv[1], &data, &len) || napi_get_value_double(env, argv[2], &n) != napi_ok ||
+        (double)len < n * GS_SPLAT_RECORD_BYTES) {
+        napi_throw_type_error(env, NULL, "gsplat.uploadSplats: need n*320 bytes");
+        return NULL;
+    }
+    int32_t rc = gs_upload_splats(ctx, data, (uint64_t)n);
+    return rc == GS_OK ? NULL : throw_gs(env, rc);
+}
+
+/* renderSync(handle, uniforms160[, debug]) : enqueue + wait on the calling thread */
+static napi_value js_render_sync(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 2 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    void* data = NULL;
+    size_t len = 0;
+    if (!get_bytes(env, argv[1], &data, &len) || len < GS_UNIFORM_BYTES) {
+        napi_throw_type_error(env, NULL, "gsplat.render: need the 160-byte uniform block");
+        return NULL;
+    }
+    bool debug = false;
+    if (argc >= 3) napi_get_value_bool(env, argv[2], &debug);
+    int32_t rc = debug ? gs_render_debug(ctx, data) : gs_render(ctx, data);
+    if (rc == GS_OK) rc = gs_wait(ctx);
+    return rc == GS_OK ? NULL : throw_gs(env, rc);
+}
+
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    gs_ctx* ctx;
+    unsigned char uniforms[GS_UNIFORM_BYTES];
+    int32_t rc;
+    char err[512];
+} frame_job;
+
+static void job_execute(napi_env env, void* data) {
+    (void)env;
+    frame_job* j = (frame_job*)data;
+    j->rc = gs_render(j->ctx, j->uniforms);
+    if (j->rc == GS_OK) j->rc = gs_wait(j->ctx);
+    if (j->rc != GS_OK) { /* gs_last_error is thread-local: capture it on the worker thread */
+        strncpy(j->err, gs_last_error(), sizeof(j->err) - 1);
+        j->err[sizeof(j->err) - 1] = 0;
+    }
+}
+
+static void job_complete(napi_env env, napi_status status, void* data) {
+    frame_job* j = (frame_job*)data;
+    napi_value v;
+    if (status == napi_ok && j->rc == GS_OK) {
+        napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg;
+        napi_create_string_utf8(env, j->rc != GS_OK ? j->err : "gsplat: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &v);
+        napi_reject_deferred(env, j->deferred, v);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+/* renderAsync(handle, uniforms160) -> Promise<void> */
+static napi_value js_render_async(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 2 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    void* data = NULL;
+    size_t len = 0;
+    if (!get_bytes(env, argv[1], &data, &len) || len < GS_UNIFORM_BYTES) {
+        napi_throw_type_error(env, NULL, "gsplat.renderAsync: need the 160-byte uniform block");
+        return NULL;
+    }
+    frame_job* j = (frame_job*)calloc(1, sizeof(frame_job));
+    j->ctx = ctx;
+    memcpy(j->uniforms, data, GS_UNIFORM_BYTES);
+    napi_value promise, name;
+    NAPI_CALL(env, napi_create_promise(env, &j->deferred, &promise));
+    NAPI_CALL(env, napi_create_string_utf8(env, "gsplat.frame", NAPI_AUTO_LENGTH, &name));
+    NAPI_CALL(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
+    NAPI_CALL(env, napi_queue_async_work(env, j->work));
+    return promise;
+}
+
+/* readRgba8(handle) -> ArrayBuffer (height*slabWidth*4) */
+static napi_value js_read_rgba8(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 1 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    uint64_t bytes = 0;
+    int32_t rc = gs_read_buffer(ctx, GS_BUF_RGBA8, NULL, 0, &bytes);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    void* dst = NULL;
+    napi_value ab;
+    NAPI_CALL(env, napi_create_arraybuffer(env, (size_t)bytes, &dst, &ab));
+    rc = gs_read_rgba8(ctx, dst, bytes);
+    return rc == GS_OK ? ab : throw_gs(env, rc);
+}
+
+/* readBuffer(handle, which) -> ArrayBuffer */
+static napi_value js_read_buffer(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 2 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    int32_t which = 0;
+    NAPI_CALL(env, napi_get_value_int32(env, argv[1], &which));
+    uint64_t bytes = 0;
+    int32_t rc = gs_read_buffer(ctx, which, NULL, 0, &bytes);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    void* dst = NULL;
+    napi_value ab;
+    NAPI_CALL(env, napi_create_arraybuffer(env, (size_t)bytes, &dst, &ab));
+    if (bytes) rc = gs_read_buffer(ctx, which, dst, bytes, NULL);
+    return rc == GS_OK ? ab : throw_gs(env, rc);
+}
+
+static void set_num(napi_env env, napi_value obj, const char* k, double v) {
+    napi_value n;
+    napi_create_double(env, v, &n);
+    napi_set_named_property(env, obj, k, n);
+}
+
+/* stats(handle) -> {numGaussians, numVisible, numIntersections, numProcessed, numTiles, sortPasses, frames, stageUs:[6], frameUs} */
+static napi_value js_stats(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 1 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    gs_stats st;
+    int32_t rc = gs_get_stats(ctx, &st);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    napi_value o, arr;
+    NAPI_CALL(env, napi_create_object(env, &o));
+    set_num(env, o, "numGaussians", (double)st.num_gaussians);
+    set_num(env, o, "numVisible", (double)st.num_visible);
+    set_num(env, o, "numIntersections", (double)st.num_intersections);
+    set_num(env, o, "numProcessed", (double)st.num_processed);
+    set_num(env, o, "numTiles", (double)st.num_tiles);
+    set_num(env, o, "sortPasses", (double)st.sort_passes);
+    set_num(env, o, "frames", (double)st.frames);
+    set_num(env, o, "frameUs", (double)st.frame_us);
+    NAPI_CALL(env, napi_create_array_with_length(env, GS_STAGE_COUNT, &arr));
+    for (uint32_t i = 0; i < GS_STAGE_COUNT; ++i) {
+        napi_value n;
+        napi_create_double(env, (double)st.stage_us[i], &n);
+        napi_set_element(env, arr, i, n);
+    }
+    napi_set_named_property(env, o, "stageUs", arr);
+    return o;
+}
+
+static napi_value js_slab(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 1 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    uint32_t b = 0, w = 0;
+    int32_t rc = gs_slab_width(ctx, &b, &w);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    napi_value o;
+    NAPI_CALL(env, napi_create_object(env, &o));
+    set_num(env, o, "begin", b);
+    set_num(env, o, "width", w);
+    return o;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } fns[] = {
+        {"create", js_create},       {"destroy", js_destroy},         {"uploadSplats", js_upload},
+        {"renderSync", js_render_sync}, {"renderAsync", js_render_async}, {"readRgba8", js_read_rgba8},
+        {"readBuffer", js_read_buffer}, {"stats", js_stats},             {"slab", js_slab},
+    };
+    for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        napi_set_named_property(env, exports, fns[i].name, f);
+    }
+    set_num(env, exports, "abiVersion", (double)gs_abi_version());
+    set_num(env, exports, "FLAG_EXACT_BLEND", GS_FLAG_EXACT_BLEND);
+    set_num(env, exports, "FLAG_F32_TAP", GS_FLAG_F32_TAP);
+    set_num(env, exports, "FLAG_TIMING", GS_FLAG_TIMING);
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

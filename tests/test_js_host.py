@@ -1,0 +1,105 @@
+"""The Node host (gaussian-splatting-wgpu_amd/js + the N-API addon): Camera / PackedGaussians parity
+with the Python mirror on CPU, and an end-to-end Renderer.animate() frame on the GPU."""
+import json
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "tests", "js", "host_check.js")
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+def _node(*args):
+    out = subprocess.run([NODE, SCRIPT] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_camera_matches_python_mirror():
+    from gsplat.camera import Camera
+    th = 0.4
+    raw = {"id": 0, "img_name": "x", "width": 800, "height": 800, "fx": 800, "fy": 800, "position": [0.3, -1.0, 2.0],
+           "rotation": [[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]]}
+    js = _node("camera", json.dumps(raw))
+    c = Camera.default()
+    np.testing.assert_allclose(js["default"]["uniforms"], c.uniforms(800, 800), rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(np.float32(js["default"]["view"]), c.viewMatrix)
+    # the key sequence of host_check.js: w d q (translate) then j i u (rotate), applied in one getCamera()
+    c.translate(0.1, -0.1, 0.1)
+    c.rotate(0.1, 0.1, 0.1)
+    np.testing.assert_allclose(js["moved"]["uniforms"], c.uniforms(640, 480), rtol=1e-5, atol=1e-5)
+    assert js["dirtyAfter"] is False
+    cj = Camera.from_json(raw)
+    np.testing.assert_allclose(js["fromJSON"]["uniforms"], cj.uniforms(800, 800), rtol=1e-5, atol=1e-5)
+
+
+def _write_ply(path, n, degree, with_uchar=False, seed=0):
+    rng = np.random.default_rng(seed)
+    nrest = 3 * ((degree + 1) ** 2 - 1)
+    props = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + ["f_rest_%d" % i for i in range(nrest)] + \
+            ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n
+    for p in props:
+        header += "property float %s\n" % p
+    if with_uchar:
+        header += "property uchar red\n"
+    header += "end_header\n"
+    data = rng.standard_normal((n, len(props))).astype(np.float32)
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        for i in range(n):
+            f.write(data[i].tobytes())
+            if with_uchar:
+                f.write(struct.pack("B", i % 256))
+    return props, data
+
+
+@pytest.mark.parametrize("degree,uchar", [(3, False), (3, True), (1, False), (0, False)])
+def test_ply_loader_packs_reference_layout(tmp_path, degree, uchar):
+    """ply.ts:162-228: record = pos@0, log_scale@16, rot@32, opacity@48, sh@64 (16 B per coefficient),
+    SH order f_dc then f_rest_{rgb*K+i}; lower degrees zero-padded to 16 coefficients."""
+    n = 37
+    ply = str(tmp_path / "pc.ply")
+    props, data = _write_ply(ply, n, degree, uchar, seed=degree)
+    out = str(tmp_path / "rec.bin")
+    info = _node("ply", ply, out)
+    assert info["n"] == n and info["degree"] == degree and info["size"] == n * 320
+    rec = np.fromfile(out, dtype=np.float32).reshape(n, 80)
+    col = {p: data[:, i] for i, p in enumerate(props)}
+    np.testing.assert_array_equal(rec[:, 0:3], np.stack([col["x"], col["y"], col["z"]], 1))
+    np.testing.assert_array_equal(rec[:, 4:7], np.stack([col["scale_0"], col["scale_1"], col["scale_2"]], 1))
+    np.testing.assert_array_equal(rec[:, 8:12], np.stack([col["rot_%d" % i] for i in range(4)], 1))
+    np.testing.assert_array_equal(rec[:, 12], col["opacity"])
+    K = (degree + 1) ** 2 - 1
+    for c in range(3):
+        np.testing.assert_array_equal(rec[:, 16 + c], col["f_dc_%d" % c])
+        for i in range(K):
+            np.testing.assert_array_equal(rec[:, 16 + 4 * (i + 1) + c], col["f_rest_%d" % (c * K + i)])
+    assert not rec[:, 16 + 4 * (K + 1):].any() and not rec[:, 3].any() and not rec[:, 13:16].any()
+
+
+@pytest.mark.gpu
+def test_renderer_animate_end_to_end(tmp_path, oracle):
+    """new Renderer(canvas, interactiveCamera, device, gaussians, tileSize) -> animate() -> frame sink,
+    through N-API, bit-equal to the oracle (exact-blend flag)."""
+    from gsplat import synth
+    n, W, H, ts = 8000, 256, 160, 16
+    s = scene(n)
+    u = synth.orbit_camera(4, W, H).uniforms(W, H)
+    rec, ub, out = str(tmp_path / "rec.bin"), str(tmp_path / "u.bin"), str(tmp_path / "out.rgba")
+    s.tofile(rec)
+    u.tofile(ub)
+    info = _node("render", rec, n, W, H, ts, ub, out)
+    ref = oracle.render(s, u, W, H, ts)
+    assert info["frames"] == 1 and info["numIntersections"] == ref["num_intersections"]
+    assert info["nkeys"] == ref["num_intersections"] and info["key0"] == int(ref["sorted_keys"][0])
+    img = np.fromfile(out, dtype=np.uint8).reshape(H, W, 4)
+    np.testing.assert_array_equal(img, ref["rgba8"])
