@@ -71,7 +71,9 @@ struct gs_ctx {
     uint32_t* ranges = nullptr;
     uint32_t* rgba8 = nullptr;
     float* rgbf = nullptr;
-    uint32_t* d_pxb = nullptr; // assemble: pixel boundaries
+    uint32_t* d_pxb = nullptr; // assemble: pixel boundaries (device copy of pxb_host)
+    uint32_t pxb_host[65] = {};
+    uint32_t pxb_n = 0;
     hipEvent_t ev[GS_EV_RING][GS_STAGE_COUNT + 1] = {}; // ring of per-frame stage brackets (GS_FLAG_TIMING)
     bool have_events = false;
     uint64_t timed_from = 0; // first frame index included in the stage means
@@ -461,10 +463,15 @@ GS_EXPORT int32_t gs_assemble_slabs(gs_ctx* c, const void* d_slabs, const uint32
     uint32_t pxb[65];
     for (uint32_t g = 0; g <= n_slabs; ++g) pxb[g] = std::min(c->frame.width, col_bounds[g] * c->frame.tile_size);
     if (pxb[0] != 0 || pxb[n_slabs] != c->frame.width) return fail(GS_ERR_INVALID_ARGUMENT, "gs_assemble_slabs: bounds must cover the canvas");
-    HIP_TRY(hipMemcpyAsync(c->d_pxb, pxb, (n_slabs + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (c->pxb_n != n_slabs || memcmp(c->pxb_host, pxb, (n_slabs + 1) * 4) != 0) {
+        // boundaries change rarely: upload them once (synchronously), not every frame
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(c->d_pxb, pxb, (n_slabs + 1) * 4, hipMemcpyHostToDevice));
+        memcpy(c->pxb_host, pxb, (n_slabs + 1) * 4);
+        c->pxb_n = n_slabs;
+    }
     gs_launch_assemble(d_slabs, d_image, c->frame.width, c->frame.height, c->d_pxb, n_slabs, slab_stride_bytes / 4, c->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream)); // pxb is a stack buffer
     return GS_OK;
 }
 

@@ -210,35 +210,42 @@ __global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // Ranges: ranges[t] = |{ j < I : key_j/1000 <= t }| (entries with tile >= T ignored, A.6).
-// Thread j in [0, I] owns the tiles t with tile[j-1] <= t < tile[j]  (tile[-1] = 0 bound, tile[I] = T):
-// every tile is written exactly once.  Gaps longer than 64 tiles are filled by the whole wave.
+// Boundary j in [0, I] owns the tiles t with tile[j-1] <= t < tile[j]  (tile[-1] = 0 bound, tile[I] = T):
+// every tile is written exactly once, so `ranges` never needs the reference's per-frame clear.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ranges_boundary(uint32_t j, uint32_t lo, uint32_t hi, uint32_t T, uint32_t* __restrict__ ranges) {
+    if (lo > T) lo = T;
+    if (hi > T) hi = T;
+    for (uint32_t t = lo; t < hi; ++t) ranges[t] = j; // almost always empty: 42 M keys, 8 k boundaries
+}
+
+// Four consecutive sorted keys per thread (one 16-byte load + the neighbour before them), several
+// chunks in flight per thread: a pure streaming read.  Boundary j in [0, I] owns the tiles t with
+// tile[j-1] <= t < tile[j] (tile[-1] = 0, tile[I] = T).
 __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restrict__ keys, const GsControl* ctl, uint32_t capacity,
                                                          uint32_t T, uint32_t* __restrict__ ranges) {
     uint32_t I = ctl->num_intersections;
     if (I > capacity) I = capacity;
-    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t nchunks = (uint64_t)I / 4 + 1; // chunk c covers boundaries 4c .. 4c+3 (those <= I)
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    // iterate whole waves so the cooperative path sees uniform control flow
-    for (uint64_t j0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); j0 <= I; j0 += stride) {
-        const uint64_t j = j0 + lane;
-        uint32_t lo = 0, hi = 0;
-        if (j <= I) {
-            lo = (j == 0) ? 0u : keys[j - 1] / 1000u;
-            hi = (j == I) ? T : keys[j] / 1000u;
-            if (lo > T) lo = T;
-            if (hi > T) hi = T;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += stride) {
+        const uint32_t j0 = (uint32_t)(c * 4);
+        uint32_t k[4];
+        if (j0 + 4 <= I) {
+            const uint4 q = *reinterpret_cast<const uint4*>(keys + j0);
+            k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) k[i] = (j0 + i < I) ? keys[j0 + i] : 0xFFFFFFFFu;
         }
-        const bool longgap = (hi > lo) && (hi - lo > 64u);
-        if (!longgap)
-            for (uint32_t t = lo; t < hi; ++t) ranges[t] = (uint32_t)j;
-        unsigned long long m = __ballot(longgap);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t l2 = __shfl(lo, src, 64), h2 = __shfl(hi, src, 64);
-            const uint32_t jv = (uint32_t)(j0 + src);
-            for (uint32_t t = l2 + lane; t < h2; t += 64) ranges[t] = jv;
+        uint32_t prev = (j0 == 0) ? 0u : keys[j0 - 1] / 1000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t j = j0 + i;
+            if (j > I) break;
+            const uint32_t cur = (j == I) ? T : k[i] / 1000u;
+            if (cur != prev || j == I) ranges_boundary(j, prev, cur, T, ranges);
+            prev = cur;
         }
     }
 }

@@ -50,20 +50,27 @@ __device__ __forceinline__ float block_qmin(float cx, float cy, float cz, float 
 }
 
 // One workgroup per tile, TS*TS threads, one pixel per thread; wave w owns the 8x8 pixel block
-// (w % (TS/8), w / (TS/8)) of the tile.  Per batch of NT staged entries every wave first builds,
-// 64 entries at a time (one per lane), the mask of entries that can reach alpha >= 1/255 somewhere
-// in ITS 8x8 block (conservative: an entry is dropped only if op*exp(-qmin) < c255 with a margin far
-// above f32 rounding, so no output bit changes), then walks only the set bits.
+// (w % (TS/8), w / (TS/8)) of the tile.  The tile's sorted list is consumed in batches of TS*TS
+// entries through a DOUBLE-BUFFERED LDS stage: while a batch is being blended, the next batch's
+// (value -> GaussianData) gathers are already in flight in registers, so there is one barrier per
+// batch and the gather latency is covered.  Per batch every wave first builds, 64 entries at a time
+// (one per lane), the mask of entries that can reach alpha >= 1/255 somewhere in ITS 8x8 block
+// (conservative: an entry is dropped only if op*exp(-qmin) < c255 with a margin far above f32
+// rounding, so no output bit changes), then walks only the set bits with a branch-free body.
+// A finished pixel needs no flag inside the loop: by the exit criterion no later entry can pass
+// `T*(1-alpha) >= 1e-4` for it, so `done` is only evaluated between batches to skip whole waves/tiles.
 template <int TS, bool EXACT>
 __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                            const uint32_t* __restrict__ ranges, GsFrame f,
-                                                           uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl, uint32_t dbg) {
+                                                           uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
+                                                           uint32_t dbg) {
     constexpr int NT = TS * TS;
     constexpr int ROUNDS = NT / 64; // 64-entry groups per batch
     constexpr int WPR = TS / 8;     // waves per tile row
-    __shared__ float4 sA[NT]; // gx, gy, conic.x, conic.y        (fused mode: conic pre-scaled)
-    __shared__ float4 sB[NT]; // conic.z, opacity, r, g
-    __shared__ float2 sC[NT]; // b, ln(255*opacity) + margin
+    // staged entry e of a batch = three 16-byte pieces, one per 16-byte piece of the GaussianData record
+    __shared__ float4 sP0[2][NT]; // gx, gy (pixels), cull limit ln(255*opacity)+margin, -
+    __shared__ float4 sP1[2][NT]; // conic.x, conic.y, conic.z (fused mode: pre-scaled), depth
+    __shared__ float4 sP2[2][NT]; // r, g, b, opacity
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t tx = f.col0 + blockIdx.x, ty = blockIdx.y;
@@ -77,109 +84,143 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
     const float pxf = (float)gx, pyf = (float)gy;
     const float bx0f = (float)bx0, by0f = (float)by0;
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    bool done = !(gx < f.width && gy < f.height);
+    const bool outside = !(gx < f.width && gy < f.height);
+    bool done = outside;
     const float c255 = (float)(1.0 / 255.0);
     const float Wf = (float)f.width, Hf = (float)f.height;
     uint32_t staged = 0, evaluated = 0;
 
-    for (uint32_t b = start; b < end; b += NT) {
-        // barrier: the previous batch is no longer being read; stop when every pixel of the tile is final
-        if (__syncthreads_and(done ? 1 : 0)) break;
-        const uint32_t idx = b + tid;
-        if (idx < end) {
-            uint32_t g = values[idx];
-            if (dbg & 2u) g = (g & 1023u); // TIMING EXPERIMENT ONLY: gather from a cache-resident window
-            const uint4 r0 = gdata[(uint64_t)g * 4 + 0];
-            const uint4 r1 = gdata[(uint64_t)g * 4 + 1];
-            const uint4 r2 = gdata[(uint64_t)g * 4 + 2];
-            const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
-            const float op = __uint_as_float(r2.w);
-            float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
-            if (!EXACT) {
-                // fused mode: fold -0.5 and log2(e) into the conic once per entry, so that
-                // power*log2(e) = hx*dx^2 + hy*dx*dy + hz*dy^2
-                const float L = 1.44269502162933349609375f;
-                cx = (-0.5f * L) * cx;
-                cy = (-L) * cy;
-                cz = (-0.5f * L) * cz;
-            }
-            sA[tid] = make_float4(gxp, gyp, cx, cy);
-            sB[tid] = make_float4(cz, op, __uint_as_float(r2.x), __uint_as_float(r2.y));
-            // alpha >= c255  <=>  q <= ln(255*op); +0.01 keeps the cull conservative (rounding is ~1e-6)
-            sC[tid] = make_float2(__uint_as_float(r2.z), __builtin_logf(op * 255.0f) + 0.01f);
+    // Gather: a wave fetches the 64 records of its 64 entries with FOUR lanes per 64-byte record
+    // (lane = 4*rec + piece), 16 records per load instruction, so the texture-address unit sees 64
+    // full lines per batch and wave instead of 192 partial ones.  Each lane converts the piece it
+    // holds and writes it straight to its slot of the stage: no transpose, no extra buffer.
+    const uint32_t piece = lane & 3u, qrec = lane >> 2;
+    uint4 rq[4];
+    uint32_t gnext = 0; // value (gaussian id) of entry b + 2*NT + tid, fetched two batches ahead
+    auto fetch_ids = [&](uint32_t b) { gnext = (b + tid < end) ? values[b + tid] : 0u; };
+    auto fetch = [&](uint32_t b, uint32_t gval) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t rec = qrec + 16u * i; // entry (w*64 + rec) of the batch
+            uint32_t g = __shfl(gval, rec, 64);
+            if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION): gather from a cache-resident window
+            if (b + w * 64u + rec < end && piece < 3u) rq[i] = gdata[(uint64_t)g * 4 + piece];
         }
-        __syncthreads();
+    };
+    auto stage = [&](uint32_t b, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = w * 64u + qrec + 16u * i;
+            if (b + e < end) {
+                const float x = __uint_as_float(rq[i].x), y = __uint_as_float(rq[i].y), z = __uint_as_float(rq[i].z),
+                            ww = __uint_as_float(rq[i].w);
+                if (piece == 0u) {
+                    sP0[buf][e].x = x * Wf; // compute_tiles.wgsl:52
+                    sP0[buf][e].y = y * Hf;
+                } else if (piece == 1u) {
+                    // fused mode: fold -0.5 and log2(e) into the conic once per entry, so that
+                    // power*log2(e) = hx*dx^2 + hy*dx*dy + hz*dy^2
+                    const float L = 1.44269502162933349609375f;
+                    sP1[buf][e] = EXACT ? make_float4(x, y, z, ww) : make_float4((-0.5f * L) * x, (-L) * y, (-0.5f * L) * z, ww);
+                } else if (piece == 2u) {
+                    sP2[buf][e] = make_float4(x, y, z, ww);
+                    // alpha >= c255  <=>  q <= ln(255*op); +0.01 keeps the cull conservative (rounding is ~1e-6)
+                    sP0[buf][e].z = __builtin_logf(ww * 255.0f) + 0.01f;
+                }
+            }
+        }
+    };
+
+    uint32_t gcur = 0;
+    if (start < end) {
+        fetch_ids(start);
+        gcur = gnext;
+        fetch(start, gcur);
+        fetch_ids(start + NT);
+        stage(start, 0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t b = start; b < end; b += NT, buf ^= 1) {
+        const uint32_t nb = b + NT;
+        if (nb < end) {
+            gcur = gnext;
+            fetch(nb, gcur);          // in flight while this batch is blended
+            fetch_ids(nb + NT);       // ids two batches ahead: the gather above never waits for them
+        }
         const uint32_t cnt = (end - b < (uint32_t)NT) ? end - b : (uint32_t)NT;
         staged += cnt;
-        if (__ballot(!done) == 0ull) continue; // this wave's block is final (uniform per wave)
-
+        if (__ballot(!done) != 0ull && !(dbg & 4u)) { // otherwise this wave's 8x8 block is final (uniform per wave)
 #pragma unroll 1
-        for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t e0 = (uint32_t)r * 64u;
-            if (e0 >= cnt) break;
-            bool rel = false;
-            if (e0 + lane < cnt) {
-                float4 a4 = sA[e0 + lane];
-                float cz = sB[e0 + lane].x;
-                const float lim = sC[e0 + lane].y;
-                if (!EXACT) { // undo the staging scale (the margin absorbs the extra rounding)
-                    const float iL = 0.693147182464599609375f;
-                    a4.z *= -2.0f * iL;
-                    a4.w *= -iL;
-                    cz *= -2.0f * iL;
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t e0 = (uint32_t)r * 64u;
+                if (e0 >= cnt) break;
+                bool rel = false;
+                if (e0 + lane < cnt) {
+                    const float4 p0 = sP0[buf][e0 + lane];
+                    float4 p1 = sP1[buf][e0 + lane];
+                    if (!EXACT) { // undo the staging scale (the margin absorbs the extra rounding)
+                        const float iL = 0.693147182464599609375f;
+                        p1.x *= -2.0f * iL;
+                        p1.y *= -iL;
+                        p1.z *= -2.0f * iL;
+                    }
+                    const float dxhi = p0.x - bx0f, dxlo = dxhi - 7.0f, dyhi = p0.y - by0f, dylo = dyhi - 7.0f;
+                    const bool pd = (p1.x > 0.0f) && (p1.z > 0.0f) && (p1.x * p1.z - p1.y * p1.y > 0.0f);
+                    float mag;
+                    const float q = block_qmin(p1.x, p1.y, p1.z, dxlo, dxhi, dylo, dyhi, mag);
+                    rel = !pd || !(q > p0.z + 1.0e-5f * mag); // NaNs compare false -> relevant
+                    if (dbg & 1u) rel = false; // PROFILING ONLY: staging + cull cost without the pixel loop
                 }
-                const float dxhi = a4.x - bx0f, dxlo = dxhi - 7.0f, dyhi = a4.y - by0f, dylo = dyhi - 7.0f;
-                const bool pd = (a4.z > 0.0f) && (cz > 0.0f) && (a4.z * cz - a4.w * a4.w > 0.0f);
-                float mag;
-                const float q = block_qmin(a4.z, a4.w, cz, dxlo, dxhi, dylo, dyhi, mag);
-                rel = !pd || !(q > lim + 1.0e-5f * mag); // NaNs compare false -> relevant
-                if (dbg & 1u) rel = false; // TIMING EXPERIMENT ONLY: staging + cull cost without the pixel loop
-            }
-            unsigned long long m = __ballot(rel);
-            evaluated += (uint32_t)__popcll(m);
-            while (m) {
-                const uint32_t e = e0 + (uint32_t)__builtin_ctzll(m);
-                m &= m - 1ull;
-                const float4 a4 = sA[e];
-                const float4 b4 = sB[e];
-                const float colb = sC[e].x;
-                if (done) continue;
-                const float dx = a4.x - pxf, dy = a4.y - pyf;
-                if (EXACT) {
-                    const float t1 = a4.z * dx * dx, t2 = b4.x * dy * dy, t3 = a4.w * dx * dy;
-                    const float power = -0.5f * (t1 + t2) - t3;
-                    const float alpha = wg_min(0.99f, b4.y * gs_exp(power));
-                    const float test = T * (1.0f - alpha);
-                    const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
-                    cr += cond * b4.z * alpha * T;
-                    cg += cond * b4.w * alpha * T;
-                    cb += cond * colb * alpha * T;
-                    T = cond * test + (1.0f - cond) * T;
-                    if (T * (1.0f - c255) < 0.0001f) done = true;
-                } else {
-                    const float u = __builtin_fmaf(a4.z, dx, a4.w * dy);
-                    const float v = (b4.x * dy) * dy;
-                    const float p2 = __builtin_fmaf(dx, u, v);
-                    const float alpha = __builtin_fminf(0.99f, b4.y * __builtin_amdgcn_exp2f(p2));
-                    const float test = __builtin_fmaf(-T, alpha, T);
-                    if (p2 <= 0.0f && alpha >= c255 && test >= 0.0001f) {
-                        const float wgt = alpha * T;
-                        cr = __builtin_fmaf(b4.z, wgt, cr);
-                        cg = __builtin_fmaf(b4.w, wgt, cg);
-                        cb = __builtin_fmaf(colb, wgt, cb);
-                        T = test;
-                        if (__builtin_fmaf(-test, c255, test) < 0.0001f) done = true;
+                unsigned long long m = __ballot(rel);
+                evaluated += (uint32_t)__popcll(m);
+                while (m) {
+                    const uint32_t e = e0 + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const float4 p0 = sP0[buf][e];
+                    const float4 p1 = sP1[buf][e];
+                    const float4 p2v = sP2[buf][e];
+                    const float dx = p0.x - pxf, dy = p0.y - pyf;
+                    if (EXACT) {
+                        const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
+                        const float power = -0.5f * (t1 + t2) - t3;
+                        const float alpha = wg_min(0.99f, p2v.w * gs_exp(power));
+                        const float test = T * (1.0f - alpha);
+                        const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
+                        cr += cond * p2v.x * alpha * T;
+                        cg += cond * p2v.y * alpha * T;
+                        cb += cond * p2v.z * alpha * T;
+                        T = cond * test + (1.0f - cond) * T;
+                    } else {
+                        const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
+                        const float v = (p1.z * dy) * dy;
+                        const float pw = __builtin_fmaf(dx, u, v); // power * log2(e)
+                        const float alpha = __builtin_fminf(0.99f, p2v.w * __builtin_amdgcn_exp2f(pw));
+                        const float test = __builtin_fmaf(-T, alpha, T);
+                        const bool keep = (pw <= 0.0f) && (alpha >= c255) && (test >= 0.0001f);
+                        const float ak = keep ? alpha : 0.0f;
+                        const float wgt = ak * T;
+                        cr = __builtin_fmaf(p2v.x, wgt, cr);
+                        cg = __builtin_fmaf(p2v.y, wgt, cg);
+                        cb = __builtin_fmaf(p2v.z, wgt, cb);
+                        T = keep ? test : T;
                     }
                 }
             }
+            // exit criterion: no later entry can be kept once fl(T*fl(1-c255)) < 1e-4
+            if (EXACT) done = outside || (T * (1.0f - c255) < 0.0001f);
+            else done = outside || (__builtin_fmaf(-T, c255, T) < 0.0001f);
         }
+        if (nb < end) stage(nb, buf ^ 1); // every wave finished reading buf^1 before the previous barrier
+        // one barrier per batch: publishes the next stage; stop when every pixel of the tile is final
+        if (__syncthreads_and(done ? 1 : 0)) break;
     }
-    // statistic: spread over 64 words so that 8 160+ tiles do not serialise on one atomic
+    // statistics: spread over 64 words so that 8 160+ tiles do not serialise on one atomic
     if (tid == 0 && staged) atomicAdd(&ctl->num_processed[(blockIdx.x + blockIdx.y * gridDim.x) & 63u], (unsigned long long)staged);
     if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(blockIdx.x + blockIdx.y * gridDim.x + w) & 63u], (unsigned long long)evaluated);
 
     // textureStore(render_target, xy, vec4(C, 1)) to rgba8unorm (compute_tiles.wgsl:71): clamp, *255, round
-    if (gx < f.width && gy < f.height) {
+    if (!outside) {
         const float c[3] = {cr, cg, cb};
         uint32_t q = 0xFF000000u;
 #pragma unroll
@@ -194,6 +235,167 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
             rgbf[o * 3 + 0] = cr;
             rgbf[o * 3 + 1] = cg;
             rgbf[o * 3 + 2] = cb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-wave variant for 16x16 tiles: ONE wave owns the whole tile, four pixels per lane (one in
+// each 8x8 quadrant).  No workgroup barrier exists at all, so the eight waves resident on a SIMD are
+// eight independent gather -> cull -> blend pipelines that hide each other's memory latency; every
+// list entry is still gathered exactly once per tile.  Per 64-entry batch each lane converts the
+// entry it fetched, tests it against the four quadrants (four masks), parks it in the wave's private
+// LDS slot, and the wave then walks the four masks in turn.  Used when the launch has enough tiles to
+// fill the chip with whole-tile waves (otherwise the 4-wave kernel above gives more parallelism per tile).
+// ------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
+                                                            const uint32_t* __restrict__ ranges, GsFrame f,
+                                                            uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
+                                                            uint32_t dbg) {
+    constexpr int TS = 16;
+    __shared__ float4 sP0[64]; // gx, gy, -, -
+    __shared__ float4 sP1[64]; // conic (fused mode: pre-scaled), -
+    __shared__ float4 sP2[64]; // r, g, b, opacity
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tx = f.col0 + blockIdx.x, ty = blockIdx.y;
+    const uint32_t tile = tx + ty * f.ntx;
+    const uint32_t start = tile > 0 ? ranges[tile - 1] : 0u;
+    uint32_t end = ranges[tile];
+    if (end > f.capacity) end = f.capacity;
+    const float c255 = (float)(1.0 / 255.0);
+    const float Wf = (float)f.width, Hf = (float)f.height;
+    const float tx0f = (float)(tx * TS), ty0f = (float)(ty * TS);
+
+    float pxf[4], pyf[4], T[4], cr[4], cg[4], cb[4];
+    bool outside[4], done[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t gx = tx * TS + (q & 1) * 8 + (lane & 7), gy = ty * TS + (q >> 1) * 8 + (lane >> 3);
+        pxf[q] = (float)gx;
+        pyf[q] = (float)gy;
+        T[q] = 1.0f;
+        cr[q] = cg[q] = cb[q] = 0.0f;
+        outside[q] = !(gx < f.width && gy < f.height);
+        done[q] = outside[q];
+    }
+    uint32_t staged = 0, evaluated = 0;
+
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    uint32_t gnext = 0;
+    auto fetch_id = [&](uint32_t b) { gnext = (b + lane < end) ? values[b + lane] : 0u; };
+    auto fetch = [&](uint32_t b, uint32_t g) {
+        if (b + lane < end) {
+            if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
+            r0 = gdata[(uint64_t)g * 4 + 0];
+            r1 = gdata[(uint64_t)g * 4 + 1];
+            r2 = gdata[(uint64_t)g * 4 + 2];
+        }
+    };
+    if (start < end) {
+        fetch_id(start);
+        fetch(start, gnext);
+        fetch_id(start + 64);
+    }
+    for (uint32_t b = start; b < end; b += 64) {
+        // convert the entry this lane fetched and test it against the four quadrants
+        const uint32_t cnt = (end - b < 64u) ? end - b : 64u;
+        staged += cnt;
+        bool rel[4] = {false, false, false, false};
+        if (lane < cnt) {
+            const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
+            const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
+            const float op = __uint_as_float(r2.w);
+            const float lim = __builtin_logf(op * 255.0f) + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
+            const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dxhi = gxp - (tx0f + (float)((q & 1) * 8)), dyhi = gyp - (ty0f + (float)((q >> 1) * 8));
+                float mag;
+                const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
+                rel[q] = !pd || !(qm > lim + 1.0e-5f * mag);
+            }
+            const float L = 1.44269502162933349609375f;
+            sP0[lane] = make_float4(gxp, gyp, 0.0f, 0.0f);
+            sP1[lane] = EXACT ? make_float4(cx, cy, cz, 0.0f) : make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, 0.0f);
+            sP2[lane] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
+        }
+        // next batch's gathers go out now and land while this batch is blended
+        const uint32_t nb = b + 64;
+        if (nb < end) {
+            const uint32_t g = gnext;
+            fetch(nb, g);
+            fetch_id(nb + 64);
+        }
+        // one wave: LDS writes above are visible to its own later reads (in-order LDS); compiler fence only
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool all_done = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned long long m = __ballot(rel[q] && !(dbg & 1u));
+            if (__ballot(!done[q]) == 0ull) m = 0ull; // this quadrant is final
+            evaluated += (uint32_t)__popcll(m);
+            while (m) {
+                const uint32_t e = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const float4 p0 = sP0[e];
+                const float4 p1 = sP1[e];
+                const float4 p2v = sP2[e];
+                const float dx = p0.x - pxf[q], dy = p0.y - pyf[q];
+                if (EXACT) {
+                    const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
+                    const float power = -0.5f * (t1 + t2) - t3;
+                    const float alpha = wg_min(0.99f, p2v.w * gs_exp(power));
+                    const float test = T[q] * (1.0f - alpha);
+                    const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
+                    cr[q] += cond * p2v.x * alpha * T[q];
+                    cg[q] += cond * p2v.y * alpha * T[q];
+                    cb[q] += cond * p2v.z * alpha * T[q];
+                    T[q] = cond * test + (1.0f - cond) * T[q];
+                } else {
+                    const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
+                    const float v = (p1.z * dy) * dy;
+                    const float pw = __builtin_fmaf(dx, u, v); // power * log2(e)
+                    const float alpha = __builtin_fminf(0.99f, p2v.w * __builtin_amdgcn_exp2f(pw));
+                    const float test = __builtin_fmaf(-T[q], alpha, T[q]);
+                    const bool keep = (pw <= 0.0f) && (alpha >= c255) && (test >= 0.0001f);
+                    const float wgt = (keep ? alpha : 0.0f) * T[q];
+                    cr[q] = __builtin_fmaf(p2v.x, wgt, cr[q]);
+                    cg[q] = __builtin_fmaf(p2v.y, wgt, cg[q]);
+                    cb[q] = __builtin_fmaf(p2v.z, wgt, cb[q]);
+                    T[q] = keep ? test : T[q];
+                }
+            }
+            if (EXACT) done[q] = outside[q] || (T[q] * (1.0f - c255) < 0.0001f);
+            else done[q] = outside[q] || (__builtin_fmaf(-T[q], c255, T[q]) < 0.0001f);
+            all_done = all_done && done[q];
+        }
+        // the LDS slots are rewritten next iteration: all reads above have been issued by this wave already
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__ballot(!all_done) == 0ull) break; // every pixel of the tile is final (exact criterion)
+    }
+    if (lane == 0 && staged) atomicAdd(&ctl->num_processed[(blockIdx.x + blockIdx.y * gridDim.x) & 63u], (unsigned long long)staged);
+    if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(blockIdx.x + blockIdx.y * gridDim.x + 1u) & 63u], (unsigned long long)evaluated);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (outside[q]) continue;
+        const uint32_t gx = tx * TS + (q & 1) * 8 + (lane & 7), gy = ty * TS + (q >> 1) * 8 + (lane >> 3);
+        const float c[3] = {cr[q], cg[q], cb[q]};
+        uint32_t px = 0xFF000000u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = c[ch];
+            v = (v != v) ? 0.0f : wg_min(wg_max(v, 0.0f), 1.0f);
+            px |= (uint32_t)__builtin_floorf(v * 255.0f + 0.5f) << (8 * ch);
+        }
+        const uint64_t o = (uint64_t)gy * f.slab_w + (gx - f.px0);
+        rgba8[o] = px;
+        if (rgbf) {
+            rgbf[o * 3 + 0] = cr[q];
+            rgbf[o * 3 + 1] = cg[q];
+            rgbf[o * 3 + 2] = cb[q];
         }
     }
 }
@@ -230,7 +432,15 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
     const uint4* g = (const uint4*)gdata;
     switch (f.tile_size) {
     case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
-    case 16: launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
+    case 16: {
+        // ablation bit 3 forces the 4-wave kernel, bit 4 the single-wave kernel; default: whole-tile waves once
+        // the launch has >= 4 tiles per SIMD (1024 SIMDs), else the 4-wave kernel (slabs, small canvases)
+        const bool wave = (dbg & 16u) ? true : (dbg & 8u) ? false : ((uint64_t)grid.x * grid.y >= 4096u);
+        if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0; }
+        if (exact) hipLaunchKernelGGL((gs_blend_wave_kernel<true>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
+        else hipLaunchKernelGGL((gs_blend_wave_kernel<false>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
+        return 0;
+    }
     case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
     default: return -1;
     }

@@ -34,13 +34,18 @@ __global__ __launch_bounds__(256) void gs_sort_hist_kernel(const uint32_t* __res
     uint32_t n = *n_ptr;
     if (n > capacity) n = capacity;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const uint32_t k = keys[i];
+    const uint64_t nvec = n / 4;
+    auto add = [&](uint32_t k) {
         atomicAdd(&s_h[0][k & 255u], 1u);
         if (passes > 1) atomicAdd(&s_h[1][(k >> 8) & 255u], 1u);
         if (passes > 2) atomicAdd(&s_h[2][(k >> 16) & 255u], 1u);
         if (passes > 3) atomicAdd(&s_h[3][k >> 24], 1u);
+    };
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const uint4 q = reinterpret_cast<const uint4*>(keys)[i];
+        add(q.x); add(q.y); add(q.z); add(q.w);
     }
+    for (uint64_t i = nvec * 4 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) add(keys[i]);
     __syncthreads();
     for (uint32_t p = 0; p < passes; ++p) {
         const uint32_t c = s_h[p][threadIdx.x];

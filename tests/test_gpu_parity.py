@@ -81,6 +81,21 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
+@pytest.mark.parametrize("variant", [8, 16])  # GS_OPT_BLEND_ABLATION bits: 8 = force the 4-wave kernel, 16 = force the whole-tile-wave kernel
+@pytest.mark.parametrize("exact", [True, False])
+def test_blend_kernel_variants(oracle, variant, exact):
+    from gsplat import _abi
+    n, W, H = 60000, 640, 368
+    s, u = scene(n), _uniforms(W, H, step=7)
+    ref = oracle.render(s, u, W, H, 16, want_illcond=not exact)
+    r = _mk(s, W, H, 16, flags=_abi.GS_FLAG_EXACT_BLEND if exact else 0)
+    r.set_option(_abi.GS_OPT_BLEND_ABLATION, variant)
+    r.render_uniforms(u, debug=True)
+    r.wait()
+    _check_stages(r, ref, exact_image=exact)
+    r.destroy()
+
+
 def test_sort_kat_reference_testsort():
     """radix_sort/utils.ts:55-81: 8192 keys n-1-i must come out 0..n-1."""
     from gsplat import _abi
