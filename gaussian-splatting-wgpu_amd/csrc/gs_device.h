@@ -37,11 +37,10 @@ struct GsControl {
 };
 
 struct GsScene {
-    const float* px; const float* py; const float* pz;
-    const float* sx; const float* sy; const float* sz;
-    const float4* rot;
-    const float* opac;
-    const float4* sh; // [12][n]
+    const float* px; const float* py; const float* pz; // f32[N] each: all the cull reads
+    const float4* rec; // 256-byte record per gaussian, 16 x f32x4:
+                       //   [0] log-scale xyz, opacity logit   [1] rot r,x,y,z   [2..13] 48 SH floats (coefficient-major RGB)
+                       //   [14..15] padding (keeps every record on two 128-byte lines)
 };
 
 struct GsUniforms { // 160 B, renderer.ts:15-24

@@ -205,21 +205,17 @@ static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     c->n = (uint32_t)n;
     c->frame.n = (uint32_t)n;
     c->have_frame = false;
-    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane 256-byte aligned
-    const size_t bytes = np * (6 * 4 + 4 + 16 + 12 * 16);
+    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and the records 256-byte aligned
+    const size_t bytes = np * 3 * 4 + (size_t)n * 256;
     HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
     char* p = (char*)c->scene_mem;
     GsScene& s = c->scene;
     s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
-    s.sx = (float*)p; p += np * 4; s.sy = (float*)p; p += np * 4; s.sz = (float*)p; p += np * 4;
-    s.opac = (float*)p; p += np * 4;
-    s.rot = (float4*)p; p += np * 16;
-    s.sh = (float4*)p;
+    s.rec = (float4*)p;
     HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
-    // NOTE: the SH planes are indexed [plane][n] with stride n (not np) by the kernels
     if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
     HIP_TRY(hipGetLastError());
     uint64_t cap = c->cfg.max_intersections ? c->cfg.max_intersections : std::max<uint64_t>(4 * n, 1u << 22);

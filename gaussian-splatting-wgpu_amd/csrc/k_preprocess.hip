@@ -4,43 +4,44 @@
 // helpers in_frustum (:108-125), compute_cov3d (:127-162), compute_cov2d (:165-218),
 // compute_color_from_sh (:240-280), sigmoid (:282-294), getRect (:297-319).
 //
-// HBM layout (the reference keeps 320-byte AoS records, 84 B of which are padding; a lane striding
-// 320 B wastes most of every fetched line).  The scene is re-laid-out once at upload into planes:
-//   px,py,pz  f32[N] each      12 B read by EVERY gaussian (the cull needs nothing else)
-//   sx,sy,sz  f32[N] each      log-scales         } only lanes that survive the cull touch these
-//   rot       f32x4[N]         quaternion r,x,y,z }
-//   opac      f32[N]           opacity logit      }
-//   sh        f32x4[12][N]     48 SH floats, coefficient-major RGB, as 12 planes of 16 B/lane
-// so a wave's loads are 256 B (f32) or 1 KiB (f32x4) contiguous.  Algorithmic bytes per gaussian:
-// 12 (culled) or 236 (visible) read; 4 (count) + 64 (visible: GaussianData record) written.
+// HBM layout (the reference keeps 320-byte AoS records, 84 B of which are padding, and reads the whole
+// record of every gaussian, culled or not).  The scene is re-laid-out once at upload into
+//   px,py,pz  f32[N] planes      12 B read by EVERY gaussian: the frustum cull needs nothing else
+//   rec       256 B per gaussian  {log-scale, opacity | rot | 48 SH floats | pad}, 256-byte aligned
+// and the kernel runs in three phases per workgroup of 512 gaussians:
+//   1. cull on the position planes (coalesced 4-byte loads), survivors compacted through LDS;
+//   2. DENSE lanes (one survivor each) read the first 32 B of their record (scale, rot): covariance,
+//      conic, radius, rect, tile count -- and, for a tile-column slab, drop out if no instance lands in it;
+//   3. the rest of the record (opacity + 192 B of SH): colour, sigmoid, the 64-byte GaussianData store.
+// A culled gaussian costs 12 B, a visible one 12 + 224 B in full 64-byte sectors of its own record
+// (plane-per-attribute layouts drag in the neighbours' sectors: at 43 % visibility that doubled the
+// traffic), and the ~1000-instruction body runs on full waves instead of 43 %-populated ones.
+// Algorithmic bytes per gaussian: 12 (culled) or 236 (visible) read; 4 (count) + 56 (visible) written.
 // Bound: HBM.  No MFMA (no contraction on this path).
 #include "gs_device.h"
 
-// ---- upload: 320-byte AoS (ply.ts:190-198) -> planes ---------------------------------------------
-// One thread per (gaussian, 16-byte column): reads are fully coalesced over the AoS, writes are
-// 4- or 16-byte strided; runs once per scene.
+// ---- upload: 320-byte AoS (ply.ts:190-198) -> position planes + 256-byte records ------------------
+// One thread per (gaussian, 16-byte column of the source record); runs once per scene.
 __global__ __launch_bounds__(256) void gs_repack_kernel(const float4* __restrict__ aos, uint32_t n, float* px, float* py,
-                                                         float* pz, float* sx, float* sy, float* sz, float4* rot,
-                                                         float* opac, float4* sh) {
+                                                         float* pz, float* rec) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t total = (uint64_t)n * 20; // 20 float4 per record
+    const uint64_t total = (uint64_t)n * 20; // 20 float4 per source record
     if (t >= total) return;
     const uint32_t g = (uint32_t)(t / 20), c = (uint32_t)(t % 20);
     const float4 v = aos[t];
+    float* r = rec + (uint64_t)g * 64;
     if (c == 0) { px[g] = v.x; py[g] = v.y; pz[g] = v.z; }
-    else if (c == 1) { sx[g] = v.x; sy[g] = v.y; sz[g] = v.z; }
-    else if (c == 2) { rot[g] = v; }
-    else if (c == 3) { opac[g] = v.x; }
+    else if (c == 1) { r[0] = v.x; r[1] = v.y; r[2] = v.z; }
+    else if (c == 2) { r[4] = v.x; r[5] = v.y; r[6] = v.z; r[7] = v.w; }
+    else if (c == 3) { r[3] = v.x; }
     else {
-        // coefficient k = c-4 holds rgb in v.xyz; packed float index 3k..3k+2 of 48
-        const uint32_t k = c - 4;
-        float* shf = reinterpret_cast<float*>(sh);
-        const float comp[3] = {v.x, v.y, v.z};
+        const uint32_t k = c - 4; // SH coefficient k: rgb -> packed floats 3k..3k+2 of 48, at record float 8+
+        r[8 + 3 * k + 0] = v.x;
+        r[8 + 3 * k + 1] = v.y;
+        r[8 + 3 * k + 2] = v.z;
+        if (k == 15) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t f = 3 * k + j;     // 0..47
-            const uint32_t plane = f >> 2, e = f & 3;
-            shf[((uint64_t)plane * n + g) * 4 + e] = comp[j];
+            for (int j = 56; j < 64; ++j) r[j] = 0.0f;
         }
     }
 }
@@ -79,129 +80,175 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
     alias = (rx1 == f.ntx + 1u && f.col0 == 0u) ? 1u : 0u;
 }
 
+#define PRE_G 512 // gaussians per workgroup
+
 __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
                                                              uint32_t* __restrict__ tile_counts) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    uint32_t count = 0;
-    if (i < f.n) {
+    __shared__ uint32_t s_ids[PRE_G];
+    __shared__ uint32_t s_cnt[2][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t base = blockIdx.x * PRE_G;
+
+    // ---- phase 1: in_frustum (:108-125) on the position planes, survivors compacted ----
+    bool vis[2];
+    unsigned long long bal[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t i = base + k * 256 + tid;
+        vis[k] = false;
+        if (i < f.n) {
+            const float x = s.px[i], y = s.py[i], z = s.pz[i];
+            float ph[4], pv[4];
+            m4_mulv(u.proj, x, y, z, ph);
+            const float pw = 1.0f / (ph[3] + 0.0000001f);
+            const float ndx = ph[0] * pw, ndy = ph[1] * pw;
+            m4_mulv(u.view, x, y, z, pv);
+            vis[k] = !((pv[2] <= 0.2f) || (ndx <= -1.1f || ndx >= 1.1f || ndy <= -1.1f || ndy >= 1.1f));
+            if (!vis[k]) tile_counts[i] = 0u;
+        }
+        bal[k] = __ballot(vis[k]);
+        if (lane == 0) s_cnt[k][w] = (uint32_t)__popcll(bal[k]);
+    }
+    __syncthreads();
+    uint32_t nvis = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const uint32_t c = s_cnt[k][ww];
+            if (ww < (int)w) before += c;
+            nvis += c;
+        }
+        if (k == 1) before += s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+        if (vis[k]) s_ids[before + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] = k * 256 + tid;
+    }
+    __syncthreads();
+
+    // ---- phases 2 and 3: one survivor per lane ----
+    for (uint32_t v = tid; v < nvis; v += 256) {
+        const uint32_t i = base + s_ids[v];
+        const float4* rec = s.rec + (uint64_t)i * 16;
         const float x = s.px[i], y = s.py[i], z = s.pz[i];
-        // in_frustum (:108-125)
         float ph[4], pv[4];
         m4_mulv(u.proj, x, y, z, ph);
         const float pw = 1.0f / (ph[3] + 0.0000001f);
         const float ndx = ph[0] * pw, ndy = ph[1] * pw;
         m4_mulv(u.view, x, y, z, pv);
-        const bool culled = (pv[2] <= 0.2f) || (ndx <= -1.1f || ndx >= 1.1f || ndy <= -1.1f || ndy >= 1.1f);
-        if (!culled) {
-            const float uvx = (ndx * 0.5f) + 0.5f, uvy = (ndy * 0.5f) + 0.5f; // :54
-            // compute_cov3d (:127-162)
-            const float mod = u.scale_modifier;
-            const float sc[3] = {gs_exp(s.sx[i]) * mod, gs_exp(s.sy[i]) * mod, gs_exp(s.sz[i]) * mod};
-            const float4 q = s.rot[i];
-            const float len = __builtin_sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
-            const float qr = q.x / len, qx = q.y / len, qy = q.z / len, qz = q.w / len;
-            M3 R;
-            R.m[0][0] = 1.f - 2.f * (qy * qy + qz * qz); R.m[0][1] = 2.f * (qx * qy - qr * qz); R.m[0][2] = 2.f * (qx * qz + qr * qy);
-            R.m[1][0] = 2.f * (qx * qy + qr * qz); R.m[1][1] = 1.f - 2.f * (qx * qx + qz * qz); R.m[1][2] = 2.f * (qy * qz - qr * qx);
-            R.m[2][0] = 2.f * (qx * qz - qr * qy); R.m[2][1] = 2.f * (qy * qz + qr * qx); R.m[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
-            M3 M;
+        const float uvx = (ndx * 0.5f) + 0.5f, uvy = (ndy * 0.5f) + 0.5f; // :54
+        // compute_cov3d (:127-162)
+        const float4 so = rec[0]; // log-scale xyz, opacity logit
+        const float4 q = rec[1];
+        const float mod = u.scale_modifier;
+        const float sc[3] = {gs_exp(so.x) * mod, gs_exp(so.y) * mod, gs_exp(so.z) * mod};
+        const float len = __builtin_sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+        const float qr = q.x / len, qx = q.y / len, qy = q.z / len, qz = q.w / len;
+        M3 R;
+        R.m[0][0] = 1.f - 2.f * (qy * qy + qz * qz); R.m[0][1] = 2.f * (qx * qy - qr * qz); R.m[0][2] = 2.f * (qx * qz + qr * qy);
+        R.m[1][0] = 2.f * (qx * qy + qr * qz); R.m[1][1] = 1.f - 2.f * (qx * qx + qz * qz); R.m[1][2] = 2.f * (qy * qz - qr * qx);
+        R.m[2][0] = 2.f * (qx * qz - qr * qy); R.m[2][1] = 2.f * (qy * qz + qr * qx); R.m[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
+        M3 M;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) M.m[c][r] = sc[r] * R.m[c][r];
-            const M3 Sig = m3_mul(m3_t(M), M);
-            // compute_cov2d (:165-218)
-            float t0 = pv[0], t1 = pv[1];
-            const float t2 = pv[2];
-            const float limx = 1.3f * u.tan_fovx, limy = 1.3f * u.tan_fovy;
-            t0 = wg_min(limx, wg_max(-limx, t0 / t2)) * t2;
-            t1 = wg_min(limy, wg_max(-limy, t1 / t2)) * t2;
-            M3 J;
-            J.m[0][0] = u.focal_x / t2; J.m[0][1] = 0.f; J.m[0][2] = -(u.focal_x * t0) / (t2 * t2);
-            J.m[1][0] = 0.f; J.m[1][1] = u.focal_y / t2; J.m[1][2] = -(u.focal_y * t1) / (t2 * t2);
-            J.m[2][0] = 0.f; J.m[2][1] = 0.f; J.m[2][2] = 0.f;
-            M3 Wm; // W[c][r] = V[r][c]
+            for (int r = 0; r < 3; ++r) M.m[c][r] = sc[r] * R.m[c][r];
+        const M3 Sig = m3_mul(m3_t(M), M);
+        // compute_cov2d (:165-218)
+        float t0 = pv[0], t1 = pv[1];
+        const float t2 = pv[2];
+        const float limx = 1.3f * u.tan_fovx, limy = 1.3f * u.tan_fovy;
+        t0 = wg_min(limx, wg_max(-limx, t0 / t2)) * t2;
+        t1 = wg_min(limy, wg_max(-limy, t1 / t2)) * t2;
+        M3 J;
+        J.m[0][0] = u.focal_x / t2; J.m[0][1] = 0.f; J.m[0][2] = -(u.focal_x * t0) / (t2 * t2);
+        J.m[1][0] = 0.f; J.m[1][1] = u.focal_y / t2; J.m[1][2] = -(u.focal_y * t1) / (t2 * t2);
+        J.m[2][0] = 0.f; J.m[2][1] = 0.f; J.m[2][2] = 0.f;
+        M3 Wm; // W[c][r] = V[r][c]
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) Wm.m[c][r] = u.view[r * 4 + c];
-            const M3 T = m3_mul(Wm, J);
-            M3 Vrk;
-            Vrk.m[0][0] = Sig.m[0][0]; Vrk.m[0][1] = Sig.m[0][1]; Vrk.m[0][2] = Sig.m[0][2];
-            Vrk.m[1][0] = Sig.m[0][1]; Vrk.m[1][1] = Sig.m[1][1]; Vrk.m[1][2] = Sig.m[1][2];
-            Vrk.m[2][0] = Sig.m[0][2]; Vrk.m[2][1] = Sig.m[1][2]; Vrk.m[2][2] = Sig.m[2][2];
-            const M3 cov = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
-            const float ca = cov.m[0][0] + 0.3f, cb = cov.m[0][1], cc = cov.m[1][1] + 0.3f;
-            const float det = ca * cc - cb * cb;
-            if (det != 0.0f) { // :60 (det == 0 -> count 0)
-                const float det_inv = 1.0f / det;
-                const float conx = cc * det_inv, cony = (-cb) * det_inv, conz = ca * det_inv;
-                const float mid = 0.5f * (ca + cc);
-                const float sq = __builtin_sqrtf(wg_max(0.1f, mid * mid - det));
-                const float l1 = mid + sq, l2 = mid - sq;
-                const float radius = __builtin_ceilf(3.f * __builtin_sqrtf(wg_max(l1, l2)));
-                // getRect (:297-319)
-                const float pxs = uvx * (float)f.width, pys = uvy * (float)f.height;
-                const int ts = (int)f.tile_size, ntx = (int)f.ntx, nty = (int)f.nty;
-                const uint32_t rminx = (uint32_t)wg_mini(ntx, wg_maxi(0, f2i_sat(pxs - radius) / ts));
-                const uint32_t rminy = (uint32_t)wg_mini(nty, wg_maxi(0, f2i_sat(pys - radius) / ts));
-                const uint32_t rmaxx = (uint32_t)(wg_mini(ntx, wg_maxi(0, f2i_sat(pxs + radius) / ts)) + 1);
-                const uint32_t rmaxy = (uint32_t)(wg_mini(nty, wg_maxi(0, f2i_sat(pys + radius) / ts)) + 1);
-                if (f.full) {
-                    count = (rmaxy - rminy) * (rmaxx - rminx); // :86
-                } else {
-                    uint32_t xa, wmain, alias;
-                    slab_cols(rminx, rmaxx, f, xa, wmain, alias);
-                    count = (rmaxy - rminy) * (wmain + alias);
-                }
-                // compute_color_from_sh (:240-280)
-                const float dx = x - u.cam[0], dy = y - u.cam[1], dz = z - u.cam[2];
-                const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
-                const float X = dx / dl, Y = dy / dl, Z = dz / dl;
-                const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, xz = X * Z, yz = Y * Z;
-                float k[16];
-                k[4] = 1.0925484305920792f * xy;
-                k[5] = -1.0925484305920792f * yz;
-                k[6] = 0.31539156525252005f * ((2.f * zz - xx) - yy);
-                k[7] = -1.0925484305920792f * xz;
-                k[8] = 0.5462742152960396f * (xx - yy);
-                k[9] = (-0.5900435899266435f * Y) * (3.f * xx - yy);
-                k[10] = (2.890611442640554f * xy) * Z;
-                k[11] = (-0.4570457994644658f * Y) * ((4.f * zz - xx) - yy);
-                k[12] = (0.3731763325901154f * Z) * ((2.f * zz - 3.f * xx) - 3.f * yy);
-                k[13] = (-0.4570457994644658f * X) * ((4.f * zz - xx) - yy);
-                k[14] = (1.445305721320277f * Z) * (xx - yy);
-                k[15] = (-0.5900435899266435f * X) * (xx - 3.f * yy);
-                float shv[48];
-#pragma unroll
-                for (int p = 0; p < 12; ++p) {
-                    const float4 v = s.sh[(uint64_t)p * f.n + i];
-                    shv[4 * p + 0] = v.x; shv[4 * p + 1] = v.y; shv[4 * p + 2] = v.z; shv[4 * p + 3] = v.w;
-                }
-                float col[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float res = 0.28209479177387814f * shv[c];
-                    res = res + 0.4886025119029199f * ((((-Y) * shv[3 + c]) + Z * shv[6 + c]) - X * shv[9 + c]);
-#pragma unroll
-                    for (int j = 4; j < 16; ++j) res = res + k[j] * shv[3 * j + c];
-                    res = res + 0.5f;
-                    col[c] = wg_max(res, 0.0f);
-                }
-                // sigmoid (:282-294): both branches evaluated, blended by a 0/1 float
-                const float o = s.opac[i];
-                const float ez = gs_exp(o);
-                const float cond = (o >= 0.0f) ? 1.0f : 0.0f;
-                const float opacity = (cond * (1.0f / (1.0f + gs_exp(-o)))) + ((1.0f - cond) * (ez / (1.0f + ez)));
-                // GaussianData record (:97-104), 64 B as four 16-byte stores
-                uint4* o4 = gdata + (uint64_t)i * 4;
-                o4[0] = make_uint4(__float_as_uint(uvx), __float_as_uint(uvy), 0u, 0u);
-                o4[1] = make_uint4(__float_as_uint(conx), __float_as_uint(cony), __float_as_uint(conz), __float_as_uint(pv[2]));
-                o4[2] = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[1]), __float_as_uint(col[2]), __float_as_uint(opacity));
-                o4[3] = make_uint4(rminx, rminy, rmaxx, rmaxy);
+            for (int r = 0; r < 3; ++r) Wm.m[c][r] = u.view[r * 4 + c];
+        const M3 Tm = m3_mul(Wm, J);
+        M3 Vrk;
+        Vrk.m[0][0] = Sig.m[0][0]; Vrk.m[0][1] = Sig.m[0][1]; Vrk.m[0][2] = Sig.m[0][2];
+        Vrk.m[1][0] = Sig.m[0][1]; Vrk.m[1][1] = Sig.m[1][1]; Vrk.m[1][2] = Sig.m[1][2];
+        Vrk.m[2][0] = Sig.m[0][2]; Vrk.m[2][1] = Sig.m[1][2]; Vrk.m[2][2] = Sig.m[2][2];
+        const M3 cov = m3_mul(m3_mul(m3_t(Tm), m3_t(Vrk)), Tm);
+        const float ca = cov.m[0][0] + 0.3f, cb = cov.m[0][1], cc = cov.m[1][1] + 0.3f;
+        const float det = ca * cc - cb * cb;
+        uint32_t count = 0;
+        uint32_t rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+        float conx = 0.f, cony = 0.f, conz = 0.f;
+        if (det != 0.0f) { // :60 (det == 0 -> count 0, nothing written)
+            const float det_inv = 1.0f / det;
+            conx = cc * det_inv; cony = (-cb) * det_inv; conz = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float sq = __builtin_sqrtf(wg_max(0.1f, mid * mid - det));
+            const float l1 = mid + sq, l2 = mid - sq;
+            const float radius = __builtin_ceilf(3.f * __builtin_sqrtf(wg_max(l1, l2)));
+            // getRect (:297-319)
+            const float pxs = uvx * (float)f.width, pys = uvy * (float)f.height;
+            const int ts = (int)f.tile_size, ntx = (int)f.ntx, nty = (int)f.nty;
+            rminx = (uint32_t)wg_mini(ntx, wg_maxi(0, f2i_sat(pxs - radius) / ts));
+            rminy = (uint32_t)wg_mini(nty, wg_maxi(0, f2i_sat(pys - radius) / ts));
+            rmaxx = (uint32_t)(wg_mini(ntx, wg_maxi(0, f2i_sat(pxs + radius) / ts)) + 1);
+            rmaxy = (uint32_t)(wg_mini(nty, wg_maxi(0, f2i_sat(pys + radius) / ts)) + 1);
+            if (f.full) {
+                count = (rmaxy - rminy) * (rmaxx - rminx); // :86
+            } else {
+                uint32_t xa, wmain, alias;
+                slab_cols(rminx, rmaxx, f, xa, wmain, alias);
+                count = (rmaxy - rminy) * (wmain + alias);
             }
         }
         tile_counts[i] = count;
+        if (count == 0) continue; // det == 0, or (slab mode) no instance in this rank's tile columns
+
+        // ---- phase 3: colour (:240-280) and opacity (:282-294) ----
+        const float dx = x - u.cam[0], dy = y - u.cam[1], dz = z - u.cam[2];
+        const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float X = dx / dl, Y = dy / dl, Z = dz / dl;
+        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, xz = X * Z, yz = Y * Z;
+        float k[16];
+        k[4] = 1.0925484305920792f * xy;
+        k[5] = -1.0925484305920792f * yz;
+        k[6] = 0.31539156525252005f * ((2.f * zz - xx) - yy);
+        k[7] = -1.0925484305920792f * xz;
+        k[8] = 0.5462742152960396f * (xx - yy);
+        k[9] = (-0.5900435899266435f * Y) * (3.f * xx - yy);
+        k[10] = (2.890611442640554f * xy) * Z;
+        k[11] = (-0.4570457994644658f * Y) * ((4.f * zz - xx) - yy);
+        k[12] = (0.3731763325901154f * Z) * ((2.f * zz - 3.f * xx) - 3.f * yy);
+        k[13] = (-0.4570457994644658f * X) * ((4.f * zz - xx) - yy);
+        k[14] = (1.445305721320277f * Z) * (xx - yy);
+        k[15] = (-0.5900435899266435f * X) * (xx - 3.f * yy);
+        float shv[48];
+#pragma unroll
+        for (int p = 0; p < 12; ++p) {
+            const float4 vv = rec[2 + p];
+            shv[4 * p + 0] = vv.x; shv[4 * p + 1] = vv.y; shv[4 * p + 2] = vv.z; shv[4 * p + 3] = vv.w;
+        }
+        float col[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float res = 0.28209479177387814f * shv[c];
+            res = res + 0.4886025119029199f * ((((-Y) * shv[3 + c]) + Z * shv[6 + c]) - X * shv[9 + c]);
+#pragma unroll
+            for (int j = 4; j < 16; ++j) res = res + k[j] * shv[3 * j + c];
+            res = res + 0.5f;
+            col[c] = wg_max(res, 0.0f);
+        }
+        // sigmoid: both branches evaluated, blended by a 0/1 float
+        const float o = so.w;
+        const float ez = gs_exp(o);
+        const float cond = (o >= 0.0f) ? 1.0f : 0.0f;
+        const float opacity = (cond * (1.0f / (1.0f + gs_exp(-o)))) + ((1.0f - cond) * (ez / (1.0f + ez)));
+        // GaussianData record (:97-104), 64 B as four 16-byte stores
+        uint4* o4 = gdata + (uint64_t)i * 4;
+        o4[0] = make_uint4(__float_as_uint(uvx), __float_as_uint(uvy), 0u, 0u);
+        o4[1] = make_uint4(__float_as_uint(conx), __float_as_uint(cony), __float_as_uint(conz), __float_as_uint(pv[2]));
+        o4[2] = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[1]), __float_as_uint(col[2]), __float_as_uint(opacity));
+        o4[3] = make_uint4(rminx, rminy, rmaxx, rmaxy);
     }
 }
 
@@ -211,11 +258,11 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
     const uint32_t blocks = (uint32_t)((total + 255) / 256);
     if (!blocks) return;
     hipLaunchKernelGGL(gs_repack_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)d_aos, n, (float*)s.px, (float*)s.py,
-                       (float*)s.pz, (float*)s.sx, (float*)s.sy, (float*)s.sz, (float4*)s.rot, (float*)s.opac, (float4*)s.sh);
+                       (float*)s.pz, (float*)s.rec);
 }
 void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                           hipStream_t st) {
-    const uint32_t blocks = (f.n + 255) / 256;
+    const uint32_t blocks = (f.n + PRE_G - 1) / PRE_G;
     if (!blocks) return;
     hipLaunchKernelGGL(gs_preprocess_kernel, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts);
 }

@@ -275,6 +275,12 @@ GSO_API void gso_preprocess(const float* splats, uint64_t n, const float* unifor
         uint32_t rmaxx = (uint32_t)(wmini(ntxi, wmaxi(0, f2i_sat(px + radius) / t_s)) + 1);
         uint32_t rmaxy = (uint32_t)(wmini(ntyi, wmaxi(0, f2i_sat(py + radius) / t_s)) + 1);
         (void)nty;
+        uint32_t cnt;
+        if (col0 == 0 && col1 >= ntx)
+            cnt = (rmaxy - rminy) * (rmaxx - rminx); /* :86 */
+        else
+            cnt = (rmaxy - rminy) * slab_columns(rminx, rmaxx, ntx, col0, col1);
+        if (cnt == 0) continue; /* slab mode: no instance in this rank's tile columns -> treated as culled */
         float color[3];
         color_from_sh(pos, g + 16, u->cam_pos, color);
         float opacity = sigmoid_ref(g[12]);
@@ -290,10 +296,7 @@ GSO_API void gso_preprocess(const float* splats, uint64_t n, const float* unifor
         b.f = color[2]; o[10] = b.u;
         b.f = opacity; o[11] = b.u;
         o[12] = rminx; o[13] = rminy; o[14] = rmaxx; o[15] = rmaxy;
-        if (col0 == 0 && col1 >= ntx)
-            tile_counts[i] = (rmaxy - rminy) * (rmaxx - rminx); /* :86 */
-        else
-            tile_counts[i] = (rmaxy - rminy) * slab_columns(rminx, rmaxx, ntx, col0, col1);
+        tile_counts[i] = cnt;
     }
 }
 
