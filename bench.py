@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override the gaussian count")
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--blend-ablation", type=int, default=0, help="profiling only: see GS_OPT_BLEND_ABLATION")
+    ap.add_argument("--emit-order", type=int, default=-1, help="GS_OPT_EMIT_ORDER override (0 depth-ordered, 1 index order)")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -123,6 +124,8 @@ def main():
                         stream=stream)
     del splats, pg
     torch.cuda.empty_cache()
+    if args.emit_order >= 0:
+        r.set_option(_abi.GS_OPT_EMIT_ORDER, args.emit_order)
     if args.blend_ablation:
         r.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
 

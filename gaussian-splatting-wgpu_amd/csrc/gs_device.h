@@ -23,9 +23,15 @@ struct GsFrame {
 
 // ---- device-resident control block (zeroed by one memset per frame) -----------------------------
 // Every word another workgroup polls lives here or in the status arrays that follow it.
+// tile_counts[] words: tile count in the low 22 bits, depth bucket u32(min(50*depth,999)) in the high 10
+#define GS_COUNT_BITS 22
+#define GS_COUNT_MASK 0x3FFFFFu
+
 struct GsControl {
-    uint32_t scan_ticket;     // dynamic block ids for the tile-count scan
-    uint32_t sort_ticket[4];  // dynamic tile ids, one per radix pass
+    uint32_t scan_ticket[2];  // dynamic block ids: [0] tile-count scan in index order, [1] in depth order
+    uint32_t sort_ticket[4];  // dynamic tile ids, one per radix pass of the instance sort
+    uint32_t gsort_ticket[2]; // ... of the gaussian-level sort by depth bucket
+    uint32_t pad1;
     uint32_t fault;           // set when a bounded spin gives up
     uint32_t overflow;        // set when I exceeds capacity
     uint32_t num_intersections; // I (written by the scan's last block)
@@ -33,7 +39,8 @@ struct GsControl {
     uint32_t pad0;
     unsigned long long num_processed[64]; // blend: staged list entries (64 partial sums)
     unsigned long long num_evaluated[64]; // blend: (wave, entry) pairs that survived the 8x8 cull
-    uint32_t hist[4][256];    // digit histograms -> exclusive digit bases
+    uint32_t hist[4][256];    // instance sort: digit histograms -> exclusive digit bases
+    uint32_t ghist[2][256];   // gaussian sort
 };
 
 struct GsScene {

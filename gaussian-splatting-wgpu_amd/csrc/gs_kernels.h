@@ -6,16 +6,17 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
 void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                           hipStream_t st);
 uint32_t gs_scan_blocks(uint32_t n);
-void gs_launch_scan(const uint32_t* counts, uint32_t* offsets, uint32_t n, unsigned long long* status, GsControl* ctl,
-                    uint32_t* total_out, hipStream_t st);
-void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const GsFrame& f, uint32_t* keys,
-                    uint32_t* values, GsControl* ctl, hipStream_t st);
+void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
+                    uint32_t* vkey, uint32_t* vval, unsigned long long* status, uint32_t* ticket, GsControl* ctl, uint32_t write_totals,
+                    hipStream_t st);
+void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
+                    const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
                       hipStream_t st);
 uint32_t gs_sort_tiles(uint64_t capacity);
-void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, const uint32_t* n_ptr,
-                    uint32_t capacity, uint32_t passes, uint32_t* status, uint32_t grid, hipStream_t st, uint32_t** out_keys,
-                    uint32_t** out_vals);
+void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
+                    const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
+                    uint32_t grid, hipStream_t st, uint32_t** out_keys, uint32_t** out_vals);
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
                     GsControl* ctl, bool exact, uint32_t ablation, hipStream_t st);
 void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t height, const uint32_t* d_px_bounds, uint32_t n_slabs,

@@ -44,7 +44,9 @@ struct gs_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     GsFrame frame{};
-    uint32_t T = 0, passes = 0, key_bits = 0;
+    uint32_t T = 0, passes = 0, key_bits = 0; // passes: 8-bit digits of the full key (reference-order pipeline)
+    uint32_t tile_passes = 0, tile_bits = 0;  // digits of key/1000 (depth-ordered pipeline)
+    bool index_order = true;                  // GS_OPT_EMIT_ORDER: emit in gaussian-index order like the reference (default)
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
     uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
     // scene planes
@@ -64,8 +66,11 @@ struct gs_ctx {
     void* ctl_mem = nullptr;
     size_t ctl_bytes = 0;
     GsControl* ctl = nullptr;
-    unsigned long long* scan_status = nullptr;
-    uint32_t* sort_status = nullptr;
+    unsigned long long* scan_status = nullptr;  // [2][scan blocks]
+    uint32_t* gsort_status = nullptr;           // gaussian-level sort by depth bucket
+    uint32_t* sort_status = nullptr;            // instance sort
+    uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
+    uint32_t last_passes = 0;
     GsControl* h_ctl = nullptr; // pinned
     // outputs
     uint32_t* ranges = nullptr;
@@ -114,13 +119,16 @@ static int32_t alloc_kv(gs_ctx* c, uint64_t capacity) {
     HIP_TRY(hipMalloc((void**)&c->keysB, kb));
     HIP_TRY(hipMalloc((void**)&c->valsB, kb));
     const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
-    const size_t scan_sz = (((size_t)gs_scan_blocks(c->n ? c->n : 1) + 1) * 8 + 255) & ~(size_t)255;
-    const size_t sort_sz = (size_t)c->passes * gs_sort_tiles(capacity) * 256 * 4;
-    c->ctl_bytes = ctl_sz + scan_sz + sort_sz;
+    const size_t scan_one = (((size_t)gs_scan_blocks(c->n ? c->n : 1) + 1) * 8 + 255) & ~(size_t)255;
+    const size_t scan_sz = 2 * scan_one;
+    const size_t gsort_sz = (size_t)2 * gs_sort_tiles(c->n ? c->n : 1) * 256 * 4;
+    const size_t sort_sz = (size_t)std::max(c->passes, c->tile_passes) * gs_sort_tiles(capacity) * 256 * 4;
+    c->ctl_bytes = ctl_sz + scan_sz + gsort_sz + sort_sz;
     HIP_TRY(hipMalloc(&c->ctl_mem, c->ctl_bytes));
     c->ctl = (GsControl*)c->ctl_mem;
     c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz);
-    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + scan_sz);
+    c->gsort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + scan_sz);
+    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + scan_sz + gsort_sz);
     c->capacity = capacity;
     c->frame.capacity = (uint32_t)capacity;
     return GS_OK;
@@ -158,6 +166,10 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     if (max_key > 0xFFFFFFFFull) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: tile ids overflow the 32-bit key (write_tile_ids.wgsl:29)"); }
     c->key_bits = bits_for(max_key);
     c->passes = (c->key_bits + 7) / 8;
+    const uint32_t tbits = bits_for((uint64_t)f.nty * f.ntx + f.ntx);
+    c->tile_passes = (tbits + 7) / 8;
+    c->tile_bits = (tbits + c->tile_passes - 1) / c->tile_passes;
+    if ((uint64_t)(f.ntx + 1) * (f.nty + 1) > GS_COUNT_MASK) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: canvas has too many tiles"); }
 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
@@ -189,6 +201,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_kv(c);
     hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
+    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->have_events)
@@ -201,7 +214,9 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
 
 static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
+    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB);
     c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
+    c->vkeyA = c->vvalA = c->vkeyB = c->vvalB = nullptr;
     c->n = (uint32_t)n;
     c->frame.n = (uint32_t)n;
     c->have_frame = false;
@@ -214,6 +229,10 @@ static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     s.rec = (float4*)p;
     HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->vkeyA, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->vvalA, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->vkeyB, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->vvalB, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
     if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
@@ -261,9 +280,27 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     mark(c, 0);
     gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, st);
     mark(c, 1);
-    gs_launch_scan(c->counts, c->offsets, c->n, c->scan_status, c->ctl, nullptr, st);
-    mark(c, 2);
-    gs_launch_emit(c->gdata, c->counts, c->offsets, f, c->keysA, c->valsA, c->ctl, st);
+    const uint32_t scan_blocks = gs_scan_blocks(c->n ? c->n : 1) + 1;
+    const bool by_index = debug || c->index_order;
+    if (by_index) {
+        // the reference's order: scan counts in gaussian order, emit in gaussian order, sort by the full key
+        gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        mark(c, 2);
+        gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);
+    } else {
+        // Depth-ordered emission: the key is tile*1000 + bucket, and the required order inside a tile is (bucket,
+        // gaussian index).  Sorting the N_vis visible GAUSSIANS by bucket first (stable, 10 bits, ~16x fewer elements
+        // than instances) and emitting their instances in that order leaves only the tile id for the stable instance
+        // sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
+        gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        uint32_t *gk = nullptr, *gperm = nullptr;
+        gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
+                       c->n, 2, 5, 0, c->gsort_status, c->grid_persist, st, &gk, &gperm);
+        gs_launch_scan(c->counts, gperm, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->scan_status + scan_blocks,
+                       &c->ctl->scan_ticket[1], c->ctl, 0u, st);
+        mark(c, 2);
+        gs_launch_emit(c->gdata, c->counts, c->offsets, gperm, &c->ctl->num_visible, f, c->keysA, c->valsA, c->ctl, st);
+    }
     if (debug) {
         if (!c->keysU) {
             HIP_TRY(hipMalloc((void**)&c->keysU, (size_t)c->capacity * 4));
@@ -273,8 +310,13 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         HIP_TRY(hipMemcpyAsync(c->valsU, c->valsA, (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, st));
     }
     mark(c, 3);
-    gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, &c->ctl->num_intersections, (uint32_t)c->capacity, c->passes,
-                   c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
+    if (by_index)
+        gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
+                       (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
+    else
+        gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
+                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
+    c->last_passes = by_index ? c->passes : c->tile_passes;
     mark(c, 4);
     gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist, st);
     mark(c, 5);
@@ -345,7 +387,9 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
     const uint64_t px = (uint64_t)c->frame.slab_w * c->frame.height;
     switch (which) {
     case GS_BUF_TILE_COUNTS: *ptr = c->counts; *bytes = (uint64_t)c->n * 4; return GS_OK;
-    case GS_BUF_TILE_OFFSETS: *ptr = c->offsets; *bytes = (uint64_t)c->n * 4; return GS_OK;
+    case GS_BUF_TILE_OFFSETS:
+        if (!c->last_debug && !c->index_order) return fail(GS_ERR_NO_FRAME, "the offsets tap needs gs_render_debug (index-order scan)");
+        *ptr = c->offsets; *bytes = (uint64_t)c->n * 4; return GS_OK;
     case GS_BUF_GAUSSIAN_DATA: *ptr = c->gdata; *bytes = (uint64_t)c->n * 64; return GS_OK;
     case GS_BUF_KEYS_UNSORTED:
     case GS_BUF_VALUES_UNSORTED:
@@ -375,6 +419,10 @@ GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t s
     if (!dst) return GS_OK;
     if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
     if (bytes) HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    if (which == GS_BUF_TILE_COUNTS) { // device words also carry the depth bucket in their high 10 bits
+        uint32_t* w = (uint32_t*)dst;
+        for (uint64_t i = 0; i < bytes / 4; ++i) w[i] &= GS_COUNT_MASK;
+    }
     return GS_OK;
 }
 
@@ -397,7 +445,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
     memset(out, 0, sizeof(*out));
     out->num_gaussians = c->n;
     out->num_tiles = c->T;
-    out->sort_passes = c->passes;
+    out->sort_passes = c->last_passes ? c->last_passes : (c->index_order ? c->passes : c->tile_passes);
     out->frames = c->frames;
     if (c->have_frame) {
         out->num_visible = c->h_ctl->num_visible;
@@ -446,6 +494,7 @@ GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; return GS_OK;
+    case GS_OPT_EMIT_ORDER: c->index_order = (value != 0); return GS_OK;
     default: break;
     }
     return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: bad key/value %d/%lld", key, (long long)value);
@@ -499,8 +548,8 @@ GS_EXPORT int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* va
     const uint32_t n32 = (uint32_t)n;
     TRY2(hipMemcpy(&ctl->num_intersections, &n32, 4, hipMemcpyHostToDevice));
     uint32_t *ok = nullptr, *ov = nullptr;
-    gs_launch_sort(kA, vA, kB, vB, ctl, &ctl->num_intersections, n32, passes, (uint32_t*)((char*)ctl_mem + ctl_sz),
-                   (uint32_t)prop.multiProcessorCount * 4, nullptr, &ok, &ov);
+    gs_launch_sort(kA, vA, kB, vB, ctl, ctl->sort_ticket, &ctl->hist[0][0], &ctl->num_intersections, n32, passes, 8, 0,
+                   (uint32_t*)((char*)ctl_mem + ctl_sz), (uint32_t)prop.multiProcessorCount * 4, nullptr, &ok, &ov);
     TRY2(hipGetLastError());
     TRY2(hipDeviceSynchronize());
     uint32_t fault = 0;
@@ -529,7 +578,8 @@ GS_EXPORT int32_t gs_exclusive_scan_u32(int32_t device, uint32_t* data, uint64_t
     TRY2(hipMemset(ctl_mem, 0, ctl_sz + st_sz));
     TRY2(hipMemcpy(in, data, kb, hipMemcpyHostToDevice));
     GsControl* ctl = (GsControl*)ctl_mem;
-    gs_launch_scan(in, out, (uint32_t)n, (unsigned long long*)((char*)ctl_mem + ctl_sz), ctl, nullptr, nullptr);
+    gs_launch_scan(in, nullptr, nullptr, (uint32_t)n, out, nullptr, nullptr, (unsigned long long*)((char*)ctl_mem + ctl_sz),
+                   &ctl->scan_ticket[0], ctl, 1u, nullptr);
     TRY2(hipGetLastError());
     TRY2(hipDeviceSynchronize());
     GsControl h;

@@ -24,22 +24,32 @@
 #define ST_PREFIX (2ull << 62)
 #define ST_MASK (3ull << 62)
 
-__global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                       uint32_t n, unsigned long long* status, GsControl* ctl,
-                                                       uint32_t* total_out) {
+// counts[] words are packed by the preprocess: tile count in the low 22 bits, depth bucket (the low part of
+// the sort key, write_tile_ids.wgsl:31) in the high 10.
+//   gather   : optional permutation; element k of the scan is counts[gather[k]] (depth-ordered pipeline)
+//   n_dev    : optional device word holding the element count (then n_static is only the launch bound)
+//   offsets  : optional output, exclusive prefix of the tile counts
+//   vkey/vval: optional ordered compaction of the non-zero elements: (bucket, element index)
+__global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ gather,
+                                                       const uint32_t* __restrict__ n_dev, uint32_t n_static,
+                                                       uint32_t* __restrict__ offsets, uint32_t* __restrict__ vkey,
+                                                       uint32_t* __restrict__ vval, unsigned long long* status, uint32_t* ticket,
+                                                       GsControl* ctl, uint32_t write_totals) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_wnz[4];
-    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_prefix[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_bid = atomicAdd(&ctl->scan_ticket, 1u);
+    const uint32_t n = n_dev ? *n_dev : n_static;
+    const uint32_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tid == 0) s_bid = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t bid = s_bid;
-    const uint32_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (bid >= nblocks) return; // uniform; every block that can be waited on has a lower ticket
     const uint32_t base = bid * SCAN_TILE + tid * SCAN_ITEMS;
 
     uint32_t v[SCAN_ITEMS];
-    if (base + SCAN_ITEMS <= n) {
+    if (!gather && base + SCAN_ITEMS <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(counts + base);
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS / 4; ++j) {
@@ -48,25 +58,25 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? counts[base + j] : 0u;
+        for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? counts[gather ? gather[base + j] : base + j] : 0u;
     }
-    uint32_t tsum = 0, nz = 0;
+    uint32_t tsum = 0, tnz = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) { tsum += v[j]; nz += (v[j] != 0u); }
+    for (int j = 0; j < SCAN_ITEMS; ++j) { tsum += v[j] & GS_COUNT_MASK; tnz += ((v[j] & GS_COUNT_MASK) != 0u); }
     const uint32_t incl = wave_incl_scan(tsum, lane);
-    if (lane == 63) s_wsum[w] = incl;
-    nz = wave_sum(nz);
-    if (lane == 0) s_wnz[w] = nz;
+    const uint32_t incl_nz = wave_incl_scan(tnz, lane);
+    if (lane == 63) { s_wsum[w] = incl; s_wnz[w] = incl_nz; }
     __syncthreads();
-    uint32_t wave_excl = 0, block_total = 0, block_nz = 0;
+    uint32_t wave_excl = 0, block_total = 0, wave_excl_nz = 0, block_nz = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t t = s_wsum[k];
-        if (k < (int)w) wave_excl += t;
+        const uint32_t t = s_wsum[k], z = s_wnz[k];
+        if (k < (int)w) { wave_excl += t; wave_excl_nz += z; }
         block_total += t;
-        block_nz += s_wnz[k];
+        block_nz += z;
     }
     uint32_t run = wave_excl + incl - tsum;
+    uint32_t run_nz = wave_excl_nz + incl_nz - tnz;
 
     if (w == 0) {
         const unsigned long long mine = ((unsigned long long)block_nz << 32) | (unsigned long long)block_total;
@@ -102,32 +112,44 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
         if (lane == 0) {
             if (bid > 0)
                 st_agent64(&status[bid], ST_PREFIX | ((unsigned long long)(excl_nz + block_nz) << 32) | (unsigned long long)(excl + block_total));
-            s_prefix = excl;
-            if (bid == nblocks - 1) {
+            s_prefix[0] = excl;
+            s_prefix[1] = excl_nz;
+            if (write_totals && bid == nblocks - 1) {
                 ctl->num_visible = excl_nz + block_nz;
                 ctl->num_intersections = excl + block_total;
-                if (total_out) *total_out = excl + block_total;
             }
         }
     }
     __syncthreads();
-    run += s_prefix;
+    run += s_prefix[0];
+    run_nz += s_prefix[1];
+    if (vkey) { // ordered compaction of the elements with a non-zero tile count
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) {
+            if ((v[j] & GS_COUNT_MASK) != 0u) {
+                vkey[run_nz] = v[j] >> GS_COUNT_BITS;
+                vval[run_nz] = base + j;
+                ++run_nz;
+            }
+        }
+    }
+    if (!offsets) return;
     if (base + SCAN_ITEMS <= n) {
         uint4* p = reinterpret_cast<uint4*>(offsets + base);
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS / 4; ++j) {
             uint4 q;
-            q.x = run; run += v[4 * j];
-            q.y = run; run += v[4 * j + 1];
-            q.z = run; run += v[4 * j + 2];
-            q.w = run; run += v[4 * j + 3];
+            q.x = run; run += v[4 * j] & GS_COUNT_MASK;
+            q.y = run; run += v[4 * j + 1] & GS_COUNT_MASK;
+            q.z = run; run += v[4 * j + 2] & GS_COUNT_MASK;
+            q.w = run; run += v[4 * j + 3] & GS_COUNT_MASK;
             p[j] = q;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) {
             if (base + j < n) offsets[base + j] = run;
-            run += v[j];
+            run += v[j] & GS_COUNT_MASK;
         }
     }
 }
@@ -149,27 +171,36 @@ __device__ __forceinline__ void slab_cols_emit(uint32_t rx0, uint32_t rx1, const
     alias = (rx1 == f.ntx + 1u && f.col0 == 0u) ? 1u : 0u;
 }
 
+// perm/n_dev: optional order of emission (element k of the launch is gaussian perm[k], k < *n_dev): the
+// depth-ordered pipeline emits gaussians sorted by depth bucket so that the instance sort only has to order by tile.
 __global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
-                                                       const uint32_t* __restrict__ offsets, GsFrame f,
+                                                       const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
+                                                       const uint32_t* __restrict__ n_dev, GsFrame f,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ values,
                                                        GsControl* ctl) {
     __shared__ uint32_t s_pref[4][64];
     __shared__ uint32_t s_row[4][64]; // xa | wmain<<16 | alias<<31
     __shared__ uint32_t s_yb[4][64];  // y0 | bucket<<16
+    __shared__ uint32_t s_gid[4][64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t i = blockIdx.x * 256 + tid;
-    uint32_t cnt = 0, off = 0;
-    if (i < f.n) { cnt = counts[i]; off = offsets[i]; }
+    const uint32_t k = blockIdx.x * 256 + tid;
+    const uint32_t n = n_dev ? *n_dev : f.n;
+    uint32_t cnt = 0, off = 0, i = 0, packed = 0;
+    if (k < n) {
+        i = perm ? perm[k] : k;
+        packed = counts[i];
+        cnt = packed & GS_COUNT_MASK;
+        off = offsets[k];
+    }
     const uint32_t first_off = __shfl(off, 0, 64);
-    // the last lane of the wave may be past n: its off is 0; take the run end from the inclusive scan
+    // the last lanes of the wave may be past n: take the run length from the inclusive scan
     const uint32_t incl = wave_incl_scan(cnt, lane);
     const uint32_t wave_total = __shfl(incl, 63, 64);
     if (wave_total == 0) return;
     uint32_t row = 0, yb = 0;
     if (cnt) {
         const uint4 rect = gdata[(uint64_t)i * 4 + 3];
-        const float depth = __uint_as_float(gdata[(uint64_t)i * 4 + 1].w);
-        const uint32_t bucket = f2u_sat(wg_min(50.0f * depth, 999.0f));
+        const uint32_t bucket = packed >> GS_COUNT_BITS; // u32(min(50*depth, 999)), computed by the preprocess
         uint32_t xa, wmain, alias;
         slab_cols_emit(rect.x, rect.z, f, xa, wmain, alias);
         row = xa | (wmain << 16) | (alias << 31);
@@ -178,19 +209,20 @@ __global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ 
     s_pref[w][lane] = incl - cnt; // exclusive, relative to the wave's first entry
     s_row[w][lane] = row;
     s_yb[w][lane] = yb;
+    s_gid[w][lane] = i;
     // single-wave producer/consumer of these LDS rows: no workgroup barrier needed, LDS ops of one
     // wave complete in order; the fence only stops the compiler from reordering.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t k = lane; k < wave_total; k += 64) {
-        // largest g with pref[g] <= k
+    for (uint32_t e = lane; e < wave_total; e += 64) {
+        // largest g with pref[g] <= e
         uint32_t lo = 0;
 #pragma unroll
         for (int step = 32; step >= 1; step >>= 1) {
             const uint32_t mid = lo + step;
-            if (mid < 64 && s_pref[w][mid] <= k) lo = mid;
+            if (mid < 64 && s_pref[w][mid] <= e) lo = mid;
         }
-        const uint32_t local = k - s_pref[w][lo];
+        const uint32_t local = e - s_pref[w][lo];
         const uint32_t r = s_row[w][lo], y_b = s_yb[w][lo];
         const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
         const uint32_t wtot = wmain + alias;
@@ -198,10 +230,10 @@ __global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ 
         const uint32_t x = (xx < wmain) ? xa + xx : f.ntx;
         const uint32_t y = (y_b & 0xFFFFu) + yy;
         const uint32_t key = (y * f.ntx + x) * 1000u + (y_b >> 16);
-        const uint32_t dst = first_off + k;
+        const uint32_t dst = first_off + e;
         if (dst < f.capacity) {
             keys[dst] = key;
-            values[dst] = blockIdx.x * 256 + (w << 6) + lo;
+            values[dst] = s_gid[w][lo];
         } else {
             ctl->overflow = 1u;
         }
@@ -252,17 +284,19 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restri
 
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
-void gs_launch_scan(const uint32_t* counts, uint32_t* offsets, uint32_t n, unsigned long long* status, GsControl* ctl,
-                    uint32_t* total_out, hipStream_t st) {
-    const uint32_t blocks = gs_scan_blocks(n);
+void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
+                    uint32_t* vkey, uint32_t* vval, unsigned long long* status, uint32_t* ticket, GsControl* ctl, uint32_t write_totals,
+                    hipStream_t st) {
+    const uint32_t blocks = gs_scan_blocks(n_static);
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(256), 0, st, counts, offsets, n, status, ctl, total_out);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(256), 0, st, counts, gather, n_dev, n_static, offsets, vkey, vval, status, ticket,
+                       ctl, write_totals);
 }
-void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const GsFrame& f, uint32_t* keys,
-                    uint32_t* values, GsControl* ctl, hipStream_t st) {
+void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
+                    const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st) {
     const uint32_t blocks = (f.n + 255) / 256;
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_emit_kernel, dim3(blocks), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, f, keys, values, ctl);
+    hipLaunchKernelGGL(gs_emit_kernel, dim3(blocks), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, n_dev, f, keys, values, ctl);
 }
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
                       hipStream_t st) {

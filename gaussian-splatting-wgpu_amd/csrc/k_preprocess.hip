@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniform
                 count = (rmaxy - rminy) * (wmain + alias);
             }
         }
-        tile_counts[i] = count;
+        // low 22 bits: tile count; high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
+        tile_counts[i] = count ? (count | (f2u_sat(wg_min(50.0f * pv[2], 999.0f)) << GS_COUNT_BITS)) : 0u;
         if (count == 0) continue; // det == 0, or (slab mode) no instance in this rank's tile columns
 
         // ---- phase 3: colour (:240-280) and opacity (:282-294) ----

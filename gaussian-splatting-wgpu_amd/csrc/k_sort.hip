@@ -24,10 +24,22 @@
 #define RS_FLAGS (3u << 30)
 #define RS_VALUE (~RS_FLAGS)
 
+// Digit of pass `pass`: `bits` bits of the sort word, which is the key itself (mode 0) or the key's tile id
+// key/1000 (mode 1: the depth-ordered pipeline sorts instances by tile only, see gs_runtime.hip).
+struct SortDigits {
+    uint32_t bits;    // bits per pass (<= 8)
+    uint32_t by_tile; // 0: word = key, 1: word = key / 1000
+};
+__device__ __forceinline__ uint32_t sort_digit(uint32_t key, uint32_t pass, const SortDigits& sd) {
+    // pad keys (0xFFFFFFFF, only in a tile's tail) must keep the largest digit in every pass so that they rank last
+    const uint32_t word = (sd.by_tile && key != 0xFFFFFFFFu) ? key / 1000u : key;
+    return (word >> (pass * sd.bits)) & ((1u << sd.bits) - 1u);
+}
+
 // ---- digit histograms of all passes in one read of the keys ---------------------------------------
-__global__ __launch_bounds__(256) void gs_sort_hist_kernel(const uint32_t* __restrict__ keys, GsControl* ctl,
+__global__ __launch_bounds__(256) void gs_sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist /*[passes][256]*/,
                                                             const uint32_t* __restrict__ n_ptr, uint32_t capacity,
-                                                            uint32_t passes) {
+                                                            uint32_t passes, SortDigits sd) {
     __shared__ uint32_t s_h[4][256];
     for (uint32_t k = threadIdx.x; k < 4 * 256; k += 256) (&s_h[0][0])[k] = 0;
     __syncthreads();
@@ -36,10 +48,12 @@ __global__ __launch_bounds__(256) void gs_sort_hist_kernel(const uint32_t* __res
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     const uint64_t nvec = n / 4;
     auto add = [&](uint32_t k) {
-        atomicAdd(&s_h[0][k & 255u], 1u);
-        if (passes > 1) atomicAdd(&s_h[1][(k >> 8) & 255u], 1u);
-        if (passes > 2) atomicAdd(&s_h[2][(k >> 16) & 255u], 1u);
-        if (passes > 3) atomicAdd(&s_h[3][k >> 24], 1u);
+        const uint32_t word = sd.by_tile ? k / 1000u : k;
+        const uint32_t mask = (1u << sd.bits) - 1u;
+        atomicAdd(&s_h[0][word & mask], 1u);
+        if (passes > 1) atomicAdd(&s_h[1][(word >> sd.bits) & mask], 1u);
+        if (passes > 2) atomicAdd(&s_h[2][(word >> (2 * sd.bits)) & mask], 1u);
+        if (passes > 3) atomicAdd(&s_h[3][(word >> (3 * sd.bits)) & mask], 1u);
     };
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
         const uint4 q = reinterpret_cast<const uint4*>(keys)[i];
@@ -49,22 +63,22 @@ __global__ __launch_bounds__(256) void gs_sort_hist_kernel(const uint32_t* __res
     __syncthreads();
     for (uint32_t p = 0; p < passes; ++p) {
         const uint32_t c = s_h[p][threadIdx.x];
-        if (c) atomicAdd(&ctl->hist[p][threadIdx.x], c);
+        if (c) atomicAdd(&hist[p * 256 + threadIdx.x], c);
     }
 }
 
 // ---- exclusive scan of each 256-bin histogram (one workgroup; thread d owns bin d) ----------------
-__global__ __launch_bounds__(256) void gs_sort_hist_scan_kernel(GsControl* ctl, uint32_t passes) {
+__global__ __launch_bounds__(256) void gs_sort_hist_scan_kernel(uint32_t* __restrict__ hist, uint32_t passes) {
     __shared__ uint32_t s_w[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (uint32_t p = 0; p < passes; ++p) {
-        const uint32_t c = ctl->hist[p][tid];
+        const uint32_t c = hist[p * 256 + tid];
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) s_w[w] = incl;
         __syncthreads();
         uint32_t base = 0;
         for (uint32_t k = 0; k < w; ++k) base += s_w[k];
-        ctl->hist[p][tid] = base + incl - c;
+        hist[p * 256 + tid] = base + incl - c;
         __syncthreads();
     }
 }
@@ -82,9 +96,9 @@ struct SweepShared {
 template <bool FULL>
 __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, GsControl* ctl,
-                                           uint32_t pass, uint32_t* status, uint32_t tile, uint32_t valid) {
+                                           const uint32_t* __restrict__ hist, uint32_t pass, SortDigits sd, uint32_t* status,
+                                           uint32_t tile, uint32_t valid) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t shift = pass * 8;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wbase = w * (64 * RS_ITEMS) + lane; // this lane's first slot in the tile
     const uint32_t* kp = keys_in + (uint64_t)tile * RS_TILE + wbase;
@@ -104,7 +118,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
     // rank inside the wave: peers = lanes holding the same digit (8 ballots), order = (item, lane)
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
-        const uint32_t d = (key[j] >> shift) & 255u;
+        const uint32_t d = sort_digit(key[j], pass, sd);
         uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -140,17 +154,27 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
         st_agent(my, RS_PREFIX | total);
     } else {
         st_agent(my, RS_AGG | total);
-        for (int t = (int)tile - 1; t >= 0; --t) {
-            const uint32_t* p = status + (uint64_t)t * 256 + tid;
-            uint32_t sv, spins = 0;
-            do {
-                sv = ld_agent(p);
-                if (sv & RS_FLAGS) break;
-                __builtin_amdgcn_s_sleep(1);
-            } while (++spins < GS_SPIN_LIMIT);
-            if ((sv & RS_FLAGS) == 0) { ctl->fault = 1u; break; }
-            excl += sv & RS_VALUE;
-            if ((sv & RS_FLAGS) == RS_PREFIX) break;
+        // Walk back over the predecessors' words LB at a time: the loads of one round are independent and in
+        // flight together, so a walk of k tiles costs ~k/LB L2 round trips instead of k (all resident
+        // workgroups start together, so the first tiles of a launch walk back hundreds of tiles).
+        constexpr int LB = 8;
+        bool found = false;
+        for (int t = (int)tile - 1; t >= 0 && !found; t -= LB) {
+            uint32_t sv[LB];
+#pragma unroll
+            for (int k = 0; k < LB; ++k) sv[k] = (t - k >= 0) ? ld_agent(status + (uint64_t)(t - k) * 256 + tid) : RS_PREFIX;
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                if (found) break;
+                uint32_t v = sv[k], spins = 0;
+                while ((v & RS_FLAGS) == 0 && ++spins < GS_SPIN_LIMIT) { // not published yet: poll this one word
+                    __builtin_amdgcn_s_sleep(1);
+                    v = ld_agent(status + (uint64_t)(t - k) * 256 + tid);
+                }
+                if ((v & RS_FLAGS) == 0) { ctl->fault = 1u; found = true; break; }
+                excl += v & RS_VALUE;
+                if ((v & RS_FLAGS) == RS_PREFIX) found = true;
+            }
         }
         st_agent(my, RS_PREFIX | ((excl + total) & RS_VALUE));
     }
@@ -162,7 +186,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
     sh.hist[1][tid] = dstart + c0;
     sh.hist[2][tid] = dstart + c0 + c1;
     sh.hist[3][tid] = dstart + c0 + c1 + c2;
-    sh.gbase[tid] = ctl->hist[pass][tid] + excl - dstart;
+    sh.gbase[tid] = hist[tid] + excl - dstart;
     __syncthreads();
 
     // reorder through LDS, then store each digit's run contiguously (payloads are only loaded now:
@@ -172,7 +196,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
         uint32_t v;
         if (FULL) v = vp[j * 64];
         else v = (wbase + j * 64 < valid) ? vp[j * 64] : 0u;
-        const uint32_t d = (key[j] >> shift) & 255u;
+        const uint32_t d = sort_digit(key[j], pass, sd);
         const uint32_t r = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
         const uint32_t pos = sh.hist[w][d] + r;
         sh.keys[pos] = key[j];
@@ -184,7 +208,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
         const uint32_t pos = j * 256 + tid;
         if (FULL || pos < valid) {
             const uint32_t k = sh.keys[pos];
-            const uint32_t g = sh.gbase[(k >> shift) & 255u] + pos;
+            const uint32_t g = sh.gbase[sort_digit(k, pass, sd)] + pos;
             keys_out[g] = k;
             vals_out[g] = sh.vals[pos];
         }
@@ -193,39 +217,43 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
 
 __global__ __launch_bounds__(256, 4) void gs_sort_sweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                             GsControl* ctl, const uint32_t* __restrict__ n_ptr, uint32_t capacity,
-                                                             uint32_t pass, uint32_t* status) {
+                                                             GsControl* ctl, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ hist,
+                                                             const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t pass,
+                                                             SortDigits sd, uint32_t* status) {
     __shared__ SweepShared sh;
     uint32_t n = *n_ptr;
     if (n > capacity) n = capacity;
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
     for (;;) {
-        if (threadIdx.x == 0) sh.tile = atomicAdd(&ctl->sort_ticket[pass], 1u);
+        if (threadIdx.x == 0) sh.tile = atomicAdd(ticket, 1u);
         __syncthreads();
         const uint32_t tile = sh.tile;
         if (tile >= ntiles) break; // uniform: every thread read the same ticket
         const uint32_t valid = (n - tile * RS_TILE < RS_TILE) ? n - tile * RS_TILE : RS_TILE;
-        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, pass, status, tile, valid);
-        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, pass, status, tile, valid);
+        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, hist, pass, sd, status, tile, valid);
+        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, hist, pass, sd, status, tile, valid);
         __syncthreads(); // LDS is reused by the next tile
     }
 }
 
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_sort_tiles(uint64_t capacity) { return (uint32_t)((capacity + RS_TILE - 1) / RS_TILE); }
-// Sorts `n` (device word *n_ptr) pairs; `passes` 8-bit digits starting at bit 0.  Returns in *out_keys/*out_vals which
-// of the two buffer pairs holds the result.  status: passes * gs_sort_tiles(capacity) * 256 words, zeroed by the caller;
-// ctl->hist and ctl->sort_ticket zeroed by the caller.
-void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, const uint32_t* n_ptr,
-                    uint32_t capacity, uint32_t passes, uint32_t* status, uint32_t grid, hipStream_t st, uint32_t** out_keys,
-                    uint32_t** out_vals) {
-    hipLaunchKernelGGL(gs_sort_hist_kernel, dim3(grid), dim3(256), 0, st, keysA, ctl, n_ptr, capacity, passes);
-    hipLaunchKernelGGL(gs_sort_hist_scan_kernel, dim3(1), dim3(256), 0, st, ctl, passes);
+// Sorts `n` (device word *n_ptr) pairs by `passes` digits of `bits` bits of the sort word (the key, or key/1000 when
+// by_tile).  Returns in *out_keys/*out_vals which of the two buffer pairs holds the result.  tickets[passes], hist[passes*256]
+// and status (passes * gs_sort_tiles(capacity) * 256 words) must have been zeroed by the caller.
+void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
+                    const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
+                    uint32_t grid, hipStream_t st, uint32_t** out_keys, uint32_t** out_vals) {
+    SortDigits sd;
+    sd.bits = bits;
+    sd.by_tile = by_tile;
+    hipLaunchKernelGGL(gs_sort_hist_kernel, dim3(grid), dim3(256), 0, st, keysA, hist, n_ptr, capacity, passes, sd);
+    hipLaunchKernelGGL(gs_sort_hist_scan_kernel, dim3(1), dim3(256), 0, st, hist, passes);
     const uint64_t per_pass = (uint64_t)gs_sort_tiles(capacity) * 256;
     uint32_t *ki = keysA, *vi = valsA, *ko = keysB, *vo = valsB;
     for (uint32_t p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(gs_sort_sweep_kernel, dim3(grid), dim3(256), 0, st, ki, vi, ko, vo, ctl, n_ptr, capacity, p,
-                           status + p * per_pass);
+        hipLaunchKernelGGL(gs_sort_sweep_kernel, dim3(grid), dim3(256), 0, st, ki, vi, ko, vo, ctl, tickets + p, hist + p * 256, n_ptr,
+                           capacity, p, sd, status + p * per_pass);
         uint32_t* t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
     }

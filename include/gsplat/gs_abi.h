@@ -97,7 +97,7 @@ typedef struct gs_stats {
 /* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */
 enum {
     GS_BUF_TILE_COUNTS = 0,   /* u32[N]     tileCountBuffer                                   */
-    GS_BUF_TILE_OFFSETS = 1,  /* u32[N]     tileOffsetBuffer after the scan                   */
+    GS_BUF_TILE_OFFSETS = 1,  /* u32[N]     tileOffsetBuffer after the scan (needs gs_render_debug)  */
     GS_BUF_GAUSSIAN_DATA = 2, /* 64 B x N   gaussianDataBuffer (culled records are all-zero)  */
     GS_BUF_KEYS_UNSORTED = 3, /* u32[I]     tile_ids as written by write_tile_ids (needs gs_render_debug) */
     GS_BUF_VALUES_UNSORTED = 4,
@@ -150,6 +150,11 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 #define GS_OPT_BLEND_ABLATION 1  /* PROFILING ONLY, breaks the image: bit0 = skip the per-pixel loop, bit1 = gather from a cache-resident window */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
 #define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
+#define GS_OPT_EMIT_ORDER 4      /* 1 (default): the reference's gaussian-index emission order + sort by the full key (3-4 radix
+                                    digits); 0: experimental depth-bucket emission order + tile-only instance sort (2 digits;
+                                    measured slower end to end in round 1: the gaussian-level pre-sort and the unbalanced
+                                    emission cost more than the saved sweep).  Sorted keys/values, ranges and image are
+                                    identical either way.                                                                */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
 /* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
 int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);
@@ -165,7 +170,8 @@ int32_t gs_assemble_slabs(gs_ctx* ctx, const void* d_slabs, const uint32_t* col_
 /* GPUSorter.sort (radix_sort/sort.ts:341-350): stable ascending sort of n u32 keys with u32 payloads,
  * host buffers, in place.  values may be NULL (keys only, as testSort does: radix_sort/utils.ts:55-81). */
 int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* values, uint64_t n, uint32_t key_bits);
-/* ExclusiveScanner.scan (exclusive_scan.ts:208-325): in-place exclusive scan of n u32, returns the total. */
+/* ExclusiveScanner.scan (exclusive_scan.ts:208-325): in-place exclusive scan of n u32 (each < 2^22, the
+ * sum < 2^32), returns the total. */
 int32_t gs_exclusive_scan_u32(int32_t device, uint32_t* data, uint64_t n, uint64_t* total);
 
 #ifdef __cplusplus

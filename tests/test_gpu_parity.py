@@ -25,17 +25,24 @@ def _uniforms(W, H, step=3):
     return synth.orbit_camera(step, W, H).uniforms(W, H)
 
 
-def _check_stages(r, ref, exact_image):
+def _check_stages(r, ref, exact_image, debug=True):
+    """debug=True: the frame came from gs_render_debug (the reference's gaussian-index emission order, every tap valid);
+    debug=False: from gs_render (depth-ordered emission; the unsorted / offsets taps do not exist)."""
     from gsplat import _abi
     st = r.stats()
     assert st["num_intersections"] == ref["num_intersections"]
     assert st["num_visible"] == int((ref["tile_counts"] > 0).sum())
     np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_COUNTS), ref["tile_counts"])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_OFFSETS), ref["offsets"])
-    gd = r.read_buffer(_abi.GS_BUF_GAUSSIAN_DATA).reshape(-1, 16)
-    np.testing.assert_array_equal(gd, ref["gdata"])  # floats compared as bits
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS_UNSORTED), ref["keys"])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES_UNSORTED), ref["values"])
+    if debug:
+        np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_OFFSETS), ref["offsets"])
+        gd = r.read_buffer(_abi.GS_BUF_GAUSSIAN_DATA).reshape(-1, 16)
+        np.testing.assert_array_equal(gd, ref["gdata"])  # floats compared as bits
+        np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS_UNSORTED), ref["keys"])
+        np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES_UNSORTED), ref["values"])
+    else:
+        gd = r.read_buffer(_abi.GS_BUF_GAUSSIAN_DATA).reshape(-1, 16)
+        vis = ref["tile_counts"] > 0  # records of culled gaussians are stale outside gs_render_debug
+        np.testing.assert_array_equal(gd[vis], ref["gdata"][vis])
     np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ref["sorted_keys"])
     np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), ref["sorted_values"])
     np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RANGES), ref["ranges"])
@@ -67,6 +74,13 @@ def test_frame_exact_mode(oracle, n, W, H, ts):
     r.render_uniforms(u, debug=True)
     r.wait()
     _check_stages(r, ref, exact_image=True)
+    r.render_uniforms(u)  # the product path (no debug copies, no gdata clear)
+    r.wait()
+    _check_stages(r, ref, exact_image=True, debug=False)
+    r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)  # experimental: depth-ordered emission, tile-only instance sort
+    r.render_uniforms(u)
+    r.wait()
+    _check_stages(r, ref, exact_image=True, debug=False)
     r.destroy()
 
 
@@ -78,6 +92,9 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.render_uniforms(u, debug=True)
     r.wait()
     _check_stages(r, ref, exact_image=False)
+    r.render_uniforms(u)
+    r.wait()
+    _check_stages(r, ref, exact_image=False, debug=False)
     r.destroy()
 
 
@@ -90,9 +107,9 @@ def test_blend_kernel_variants(oracle, variant, exact):
     ref = oracle.render(s, u, W, H, 16, want_illcond=not exact)
     r = _mk(s, W, H, 16, flags=_abi.GS_FLAG_EXACT_BLEND if exact else 0)
     r.set_option(_abi.GS_OPT_BLEND_ABLATION, variant)
-    r.render_uniforms(u, debug=True)
+    r.render_uniforms(u)
     r.wait()
-    _check_stages(r, ref, exact_image=exact)
+    _check_stages(r, ref, exact_image=exact, debug=False)
     r.destroy()
 
 
@@ -210,6 +227,8 @@ def test_slab_union_equals_full_frame(oracle):
         r.render_uniforms(u, debug=True); r.wait()
         ref = oracle.render(s, u, W, H, 16, cols=(c0, c1))
         _check_stages(r, ref, exact_image=True)
+        r.render_uniforms(u); r.wait()
+        _check_stages(r, ref, exact_image=True, debug=False)
         parts.append(r.read_rgba8())
         r.destroy()
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), img)
