@@ -76,10 +76,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
-    ap.add_argument("--n", type=int, default=0, help="override the gaussian count")
+    ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count")
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--blend-ablation", type=int, default=0, help="profiling only: see GS_OPT_BLEND_ABLATION")
     ap.add_argument("--emit-order", type=int, default=-1, help="GS_OPT_EMIT_ORDER override (0 depth-ordered, 1 index order)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -93,8 +95,8 @@ def main():
     from gsplat import _abi, synth
 
     cfg = dict(CONFIGS[args.config])
-    if args.n:
-        cfg["n"] = args.n
+    if args.gaussians:
+        cfg["n"] = args.gaussians
     N, W, H, ts = cfg["n"], cfg["width"], cfg["height"], args.tile
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,11 +106,16 @@ def main():
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     seed = synth.BASE_SEED + {"A": 0, "B": 1, "C": 2, "E": 4}[args.config]
     from gsplat import multigpu
@@ -201,7 +208,8 @@ def main():
                                 "rank0_slab_only": world > 1}
             bus = st["stage_us_mean"]["blend"]
             if bus > 0:
-                flops = 24.0 * (ts * ts) * st["num_processed"]  # 22 flop + 1 exp (counted 2) per pixel x staged entry
+                # 22 flop + 1 exp (counted 2) per pixel x entry actually evaluated (64 pixels per surviving (8x8 block, entry) pair)
+                flops = 24.0 * 64.0 * st["num_evaluated"]
                 line["roofline"]["blend_valu"] = {"achieved": round(flops / (bus * 1e-6) / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                                                   "unit": "TFLOP/s", "frac": round(flops / (bus * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, 4)}
             line["stages"] = stages

@@ -18,7 +18,9 @@
 #include "gs_device.h"
 
 #define RS_ITEMS 16
-#define RS_TILE (256 * RS_ITEMS)
+#define RS_WAVES 8 // waves per workgroup: a tile is RS_WAVES * 64 * RS_ITEMS keys
+#define RS_THREADS (RS_WAVES * 64)
+#define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_AGG (1u << 30)
 #define RS_PREFIX (2u << 30)
 #define RS_FLAGS (3u << 30)
@@ -85,11 +87,11 @@ __global__ __launch_bounds__(256) void gs_sort_hist_scan_kernel(uint32_t* __rest
 
 // ---- one digit sweep ----------------------------------------------------------------------------------
 struct SweepShared {
-    uint32_t hist[4][256];  // per-wave digit counts -> exclusive offsets across waves -> + digit start
+    uint32_t hist[RS_WAVES][256];  // per-wave digit counts -> exclusive offsets across waves -> + digit start
     uint32_t gbase[256];    // global address of slot 0 of each digit's run, minus the digit's first slot
     uint32_t keys[RS_TILE];
     uint32_t vals[RS_TILE];
-    uint32_t wsum[4];
+    uint32_t wsum[4]; // inclusive digit-total sums of the four waves that own the 256 digits
     uint32_t tile;
 };
 
@@ -141,52 +143,55 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
     }
     __syncthreads();
 
-    // thread d: counts of digit d per wave -> exclusive offsets across waves, tile total
-    const uint32_t c0 = sh.hist[0][tid], c1 = sh.hist[1][tid], c2 = sh.hist[2][tid], c3 = sh.hist[3][tid];
-    const uint32_t total = c0 + c1 + c2 + c3;
-    const uint32_t incl = wave_incl_scan(total, lane);
-    if (lane == 63) sh.wsum[w] = incl;
+    // thread d (d < 256): counts of digit d per wave -> exclusive offsets across waves, tile total
+    uint32_t cw[RS_WAVES], total = 0, incl = 0, excl = 0;
+    const bool owner = tid < 256u;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) { cw[k] = sh.hist[k][tid]; total += cw[k]; }
+        incl = wave_incl_scan(total, lane);
+        if (lane == 63) sh.wsum[w] = incl;
 
-    // publish this tile's digit count, then walk back over the predecessors' words
-    uint32_t* my = status + (uint64_t)tile * 256 + tid;
-    uint32_t excl = 0;
-    if (tile == 0) {
-        st_agent(my, RS_PREFIX | total);
-    } else {
-        st_agent(my, RS_AGG | total);
-        // Walk back over the predecessors' words LB at a time: the loads of one round are independent and in
-        // flight together, so a walk of k tiles costs ~k/LB L2 round trips instead of k (all resident
-        // workgroups start together, so the first tiles of a launch walk back hundreds of tiles).
-        constexpr int LB = 8;
-        bool found = false;
-        for (int t = (int)tile - 1; t >= 0 && !found; t -= LB) {
-            uint32_t sv[LB];
+        // publish this tile's digit count, then walk back over the predecessors' words
+        uint32_t* my = status + (uint64_t)tile * 256 + tid;
+        if (tile == 0) {
+            st_agent(my, RS_PREFIX | total);
+        } else {
+            st_agent(my, RS_AGG | total);
+            // Walk back over the predecessors' words LB at a time: the loads of one round are independent and in
+            // flight together, so a walk of k tiles costs ~k/LB L2 round trips instead of k (all resident
+            // workgroups start together, so the first tiles of a launch walk back hundreds of tiles).
+            constexpr int LB = 8;
+            bool found = false;
+            for (int t = (int)tile - 1; t >= 0 && !found; t -= LB) {
+                uint32_t sv[LB];
 #pragma unroll
-            for (int k = 0; k < LB; ++k) sv[k] = (t - k >= 0) ? ld_agent(status + (uint64_t)(t - k) * 256 + tid) : RS_PREFIX;
+                for (int k = 0; k < LB; ++k) sv[k] = (t - k >= 0) ? ld_agent(status + (uint64_t)(t - k) * 256 + tid) : RS_PREFIX;
 #pragma unroll
-            for (int k = 0; k < LB; ++k) {
-                if (found) break;
-                uint32_t v = sv[k], spins = 0;
-                while ((v & RS_FLAGS) == 0 && ++spins < GS_SPIN_LIMIT) { // not published yet: poll this one word
-                    __builtin_amdgcn_s_sleep(1);
-                    v = ld_agent(status + (uint64_t)(t - k) * 256 + tid);
+                for (int k = 0; k < LB; ++k) {
+                    if (found) break;
+                    uint32_t v = sv[k], spins = 0;
+                    while ((v & RS_FLAGS) == 0 && ++spins < GS_SPIN_LIMIT) { // not published yet: poll this one word
+                        __builtin_amdgcn_s_sleep(1);
+                        v = ld_agent(status + (uint64_t)(t - k) * 256 + tid);
+                    }
+                    if ((v & RS_FLAGS) == 0) { ctl->fault = 1u; found = true; break; }
+                    excl += v & RS_VALUE;
+                    if ((v & RS_FLAGS) == RS_PREFIX) found = true;
                 }
-                if ((v & RS_FLAGS) == 0) { ctl->fault = 1u; found = true; break; }
-                excl += v & RS_VALUE;
-                if ((v & RS_FLAGS) == RS_PREFIX) found = true;
             }
+            st_agent(my, RS_PREFIX | ((excl + total) & RS_VALUE));
         }
-        st_agent(my, RS_PREFIX | ((excl + total) & RS_VALUE));
     }
     __syncthreads();
-    uint32_t wv = 0;
-    for (uint32_t k = 0; k < w; ++k) wv += sh.wsum[k];
-    const uint32_t dstart = wv + incl - total; // first slot of digit `tid` in the tile's sorted order
-    sh.hist[0][tid] = dstart;
-    sh.hist[1][tid] = dstart + c0;
-    sh.hist[2][tid] = dstart + c0 + c1;
-    sh.hist[3][tid] = dstart + c0 + c1 + c2;
-    sh.gbase[tid] = hist[tid] + excl - dstart;
+    if (owner) {
+        uint32_t wv = 0;
+        for (uint32_t k = 0; k < w; ++k) wv += sh.wsum[k];
+        uint32_t run = wv + incl - total; // first slot of digit `tid` in the tile's sorted order
+        sh.gbase[tid] = hist[tid] + excl - run;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) { sh.hist[k][tid] = run; run += cw[k]; }
+    }
     __syncthreads();
 
     // reorder through LDS, then store each digit's run contiguously (payloads are only loaded now:
@@ -205,7 +210,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
-        const uint32_t pos = j * 256 + tid;
+        const uint32_t pos = j * RS_THREADS + tid;
         if (FULL || pos < valid) {
             const uint32_t k = sh.keys[pos];
             const uint32_t g = sh.gbase[sort_digit(k, pass, sd)] + pos;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
     }
 }
 
-__global__ __launch_bounds__(256, 4) void gs_sort_sweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              GsControl* ctl, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t pass,
@@ -252,7 +257,7 @@ void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t*
     const uint64_t per_pass = (uint64_t)gs_sort_tiles(capacity) * 256;
     uint32_t *ki = keysA, *vi = valsA, *ko = keysB, *vo = valsB;
     for (uint32_t p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(gs_sort_sweep_kernel, dim3(grid), dim3(256), 0, st, ki, vi, ko, vo, ctl, tickets + p, hist + p * 256, n_ptr,
+        hipLaunchKernelGGL(gs_sort_sweep_kernel, dim3(grid), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, ctl, tickets + p, hist + p * 256, n_ptr,
                            capacity, p, sd, status + p * per_pass);
         uint32_t* t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
