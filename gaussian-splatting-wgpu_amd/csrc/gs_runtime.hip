@@ -520,6 +520,130 @@ GS_EXPORT int32_t gs_assemble_slabs(gs_ctx* c, const void* d_slabs, const uint32
     return GS_OK;
 }
 
+// ---- native PLY loader ---------------------------------------------------------------
+// Restates PackedGaussians (reference src/ply.ts:49-228) in C++: header rules of decodeHeader (:49-102: `element
+// vertex N`, properties in file order, data right after "end_header\n"), readRawVertex (:104-123: ONLY float and
+// uchar properties consume bytes; uchar is value/255), the SH read order f_dc_{0..2} then f_rest_{rgb*K+i}
+// (:179-187), degree from the f_rest count (:168-176), and the packed 320-byte record (:190-198).  Degrees < 3 are
+// zero-padded to 16 coefficients (the shader hard-codes 16: process_gaussians.wgsl:6).  The reference spends
+// "seconds to a couple of minutes" here in JS (index.html:16); this is a single pass over a read() of the file.
+#include <string>
+#include <vector>
+
+struct PlyProp { std::string name; int type; /* 0 other (0 bytes), 1 float, 2 uchar */ uint32_t offset; };
+
+GS_EXPORT int32_t gs_ply_load(const char* path, void** records, uint64_t* n_out, int32_t* sh_degree) {
+    if (!path || !records || !n_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: null argument");
+    *records = nullptr;
+    *n_out = 0;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: cannot open %s", path);
+    fseek(fp, 0, SEEK_END);
+    const long fsize = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<unsigned char> buf((size_t)std::max<long>(fsize, 0));
+    if (fsize > 0 && fread(buf.data(), 1, (size_t)fsize, fp) != (size_t)fsize) { fclose(fp); return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: short read"); }
+    fclose(fp);
+    static const char kEnd[] = "end_header";
+    size_t hdr_end = std::string::npos;
+    for (size_t i = 0; i + sizeof(kEnd) - 1 <= buf.size(); ++i)
+        if (memcmp(buf.data() + i, kEnd, sizeof(kEnd) - 1) == 0) { hdr_end = i; break; }
+    if (hdr_end == std::string::npos) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: no end_header");
+    const std::string header((const char*)buf.data(), hdr_end + sizeof(kEnd) - 1);
+    const size_t data_off = hdr_end + sizeof(kEnd) - 1 + 1; // the byte after "end_header" (the newline), ply.ts:94
+    uint64_t vertex_count = 0;
+    std::vector<PlyProp> props;
+    size_t pos = 0;
+    while (pos < header.size()) {
+        size_t eol = header.find('\n', pos);
+        if (eol == std::string::npos) eol = header.size();
+        std::string line = header.substr(pos, eol - pos);
+        pos = eol + 1;
+        size_t a = line.find_first_not_of(" \t\r"), b = line.find_last_not_of(" \t\r");
+        if (a == std::string::npos) continue;
+        line = line.substr(a, b - a + 1);
+        if (line.rfind("element vertex", 0) == 0) {
+            size_t d = line.find_first_of("0123456789");
+            if (d != std::string::npos) vertex_count = strtoull(line.c_str() + d, nullptr, 10);
+        } else if (line.rfind("property", 0) == 0) {
+            char w0[64], w1[64], w2[128];
+            if (sscanf(line.c_str(), "%63s %63s %127s", w0, w1, w2) == 3) {
+                int type = strcmp(w1, "float") == 0 ? 1 : strcmp(w1, "uchar") == 0 ? 2 : 0;
+                bool dup = false;
+                for (auto& p : props) if (p.name == w2) { p.type = type; dup = true; }
+                if (!dup) props.push_back({w2, type, 0});
+            }
+        } else if (line == "end_header") {
+            break;
+        }
+    }
+    uint32_t stride = 0, n_rest = 0;
+    for (auto& p : props) {
+        p.offset = stride;
+        stride += p.type == 1 ? 4u : p.type == 2 ? 1u : 0u;
+        if (p.name.rfind("f_rest_", 0) == 0) ++n_rest;
+    }
+    const uint32_t per_color = n_rest / 3;
+    int degree = -1;
+    for (int d = 0; d <= 3; ++d) if ((uint32_t)((d + 1) * (d + 1) - 1) == per_color && n_rest % 3 == 0) degree = d;
+    if (degree < 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: Unsupported SH degree (%u f_rest properties)", n_rest); // ply.ts:136
+    auto find = [&](const std::string& name) -> const PlyProp* {
+        for (auto& p : props) if (p.name == name) return &p;
+        return nullptr;
+    };
+    const char* base_names[11] = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "opacity"};
+    const int base_slot[11] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 11, 12};
+    const PlyProp* src[11 + 48];
+    int slot[11 + 48];
+    int nsrc = 0;
+    for (int i = 0; i < 11; ++i) {
+        const PlyProp* p = find(base_names[i]);
+        if (!p) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: missing property %s", base_names[i]);
+        src[nsrc] = p; slot[nsrc++] = base_slot[i];
+    }
+    const int nsh = (degree + 1) * (degree + 1);
+    for (int k = 0; k < nsh; ++k)
+        for (int c = 0; c < 3; ++c) {
+            char nm[32];
+            if (k == 0) snprintf(nm, sizeof(nm), "f_dc_%d", c);
+            else snprintf(nm, sizeof(nm), "f_rest_%u", (unsigned)(c * per_color + (k - 1)));
+            const PlyProp* p = find(nm);
+            if (!p) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: missing property %s", nm);
+            src[nsrc] = p; slot[nsrc++] = 16 + 4 * k + c;
+        }
+    if (buf.size() < data_off + vertex_count * (uint64_t)stride) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: vertex data truncated");
+    float* out = (float*)calloc((size_t)std::max<uint64_t>(vertex_count, 1) * 80, sizeof(float));
+    if (!out) return fail(GS_ERR_OUT_OF_MEMORY, "gs_ply_load: out of host memory");
+    const unsigned char* v = buf.data() + data_off;
+    for (uint64_t i = 0; i < vertex_count; ++i, v += stride) {
+        float* rec = out + i * 80;
+        for (int s = 0; s < nsrc; ++s) {
+            const PlyProp* p = src[s];
+            float f = 0.0f; // a property of another type reads as `undefined` in the reference; 0 here
+            if (p->type == 1) memcpy(&f, v + p->offset, 4);
+            else if (p->type == 2) f = (float)((double)v[p->offset] / 255.0);
+            rec[slot[s]] = f;
+        }
+    }
+    *records = out;
+    *n_out = vertex_count;
+    if (sh_degree) *sh_degree = degree;
+    return GS_OK;
+}
+
+GS_EXPORT void gs_ply_free(void* records) { free(records); }
+
+GS_EXPORT int32_t gs_upload_ply(gs_ctx* c, const char* path, uint64_t* n_out) {
+    void* rec = nullptr;
+    uint64_t n = 0;
+    int32_t rc = gs_ply_load(path, &rec, &n, nullptr);
+    if (rc != GS_OK) return rc;
+    rc = gs_upload_splats(c, rec, n);
+    free(rec);
+    if (rc == GS_OK && n_out) *n_out = n;
+    return rc;
+}
+
 // ---- stand-alone stages ---------------------------------------------------------------------------------
 GS_EXPORT int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* values, uint64_t n, uint32_t key_bits) {
     if (!keys && n) return fail(GS_ERR_INVALID_ARGUMENT, "gs_sort_pairs_u32: null keys");

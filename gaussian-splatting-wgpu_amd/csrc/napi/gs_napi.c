@@ -315,11 +315,44 @@ static napi_value js_slab(napi_env env, napi_callback_info info) {
     return o;
 }
 
+/* loadPly(path) -> {n, degree, records: ArrayBuffer}: the native PackedGaussians (gs_ply_load) */
+static napi_value js_load_ply(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    char path[4096];
+    size_t len = 0;
+    if (argc < 1 || napi_get_value_string_utf8(env, argv[0], path, sizeof(path), &len) != napi_ok) {
+        napi_throw_type_error(env, NULL, "gsplat.loadPly: path required");
+        return NULL;
+    }
+    void* rec = NULL;
+    uint64_t n = 0;
+    int32_t degree = 0;
+    int32_t rc = gs_ply_load(path, &rec, &n, &degree);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    void* dst = NULL;
+    napi_value ab, o;
+    if (napi_create_arraybuffer(env, (size_t)n * GS_SPLAT_RECORD_BYTES, &dst, &ab) != napi_ok) {
+        gs_ply_free(rec);
+        napi_throw_error(env, NULL, "gsplat.loadPly: allocation failed");
+        return NULL;
+    }
+    memcpy(dst, rec, (size_t)n * GS_SPLAT_RECORD_BYTES);
+    gs_ply_free(rec);
+    NAPI_CALL(env, napi_create_object(env, &o));
+    set_num(env, o, "n", (double)n);
+    set_num(env, o, "degree", (double)degree);
+    napi_set_named_property(env, o, "records", ab);
+    return o;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", js_create},       {"destroy", js_destroy},         {"uploadSplats", js_upload},
         {"renderSync", js_render_sync}, {"renderAsync", js_render_async}, {"readRgba8", js_read_rgba8},
         {"readBuffer", js_read_buffer}, {"stats", js_stats},             {"slab", js_slab},
+        {"loadPly", js_load_ply},
     };
     for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
         napi_value f;

@@ -26,6 +26,7 @@ GS_OPT_EMIT_ORDER = 4
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
+               "gs_ply_load", "gs_ply_free", "gs_upload_ply",
                "gs_render", "gs_render_debug", "gs_render_to", "gs_wait", "gs_read_rgba8", "gs_read_buffer", "gs_device_ptr",
                "gs_get_stats", "gs_set_option", "gs_slab_width", "gs_assemble_slabs", "gs_sort_pairs_u32",
                "gs_exclusive_scan_u32")
@@ -70,6 +71,9 @@ def load():
     L.gs_destroy.argtypes = [vp]
     L.gs_upload_splats.argtypes = [vp, vp, u64]
     L.gs_upload_splats_device.argtypes = [vp, vp, u64]
+    L.gs_ply_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(i32)]
+    L.gs_ply_free.argtypes = [vp]
+    L.gs_upload_ply.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]
     L.gs_render.argtypes = [vp, vp]
     L.gs_render_debug.argtypes = [vp, vp]
     L.gs_render_to.argtypes = [vp, vp, vp]
@@ -84,8 +88,9 @@ def load():
     L.gs_sort_pairs_u32.argtypes = [i32, vp, vp, u64, u32]
     L.gs_exclusive_scan_u32.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
     for name in ABI_SYMBOLS:
-        if name != "gs_last_error":
+        if name not in ("gs_last_error", "gs_ply_free"):
             getattr(L, name).restype = i32
+    L.gs_ply_free.restype = None
     _lib = L
     return L
 
@@ -109,3 +114,15 @@ def exclusive_scan(data, device=0):
     total = ctypes.c_uint64(0)
     check(load().gs_exclusive_scan_u32(device, d.ctypes.data, d.size, ctypes.byref(total)))
     return d, int(total.value)
+
+
+def load_ply(path):
+    """Native PackedGaussians (ply.ts:162-228): returns (records float32 [n,80], sh_degree)."""
+    L = load()
+    rec, n, deg = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_int32()
+    check(L.gs_ply_load(str(path).encode(), ctypes.byref(rec), ctypes.byref(n), ctypes.byref(deg)))
+    try:
+        arr = np.ctypeslib.as_array(ctypes.cast(rec, ctypes.POINTER(ctypes.c_float)), shape=(max(n.value, 1) * 80,))[: n.value * 80]
+        return arr.reshape(n.value, 80).copy(), deg.value
+    finally:
+        L.gs_ply_free(rec)

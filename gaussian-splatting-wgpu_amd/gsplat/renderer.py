@@ -28,6 +28,15 @@ class PackedGaussians:
         self.sphericalHarmonicsDegree = 3
 
 
+    @staticmethod
+    def from_ply(path):
+        """Native loader (gs_ply_load): the reference's PackedGaussians(arrayBuffer) for a .ply on disk."""
+        rec, deg = _abi.load_ply(path)
+        pg = PackedGaussians(rec)
+        pg.sphericalHarmonicsDegree = deg
+        return pg
+
+
 class InteractiveCamera:
     """camera.ts:193-308 without the DOM callbacks: dirty flag + camera."""
 

@@ -24,6 +24,7 @@ export class PackedGaussians {
   gaussianLayout: { size: number }; gaussianArrayLayout: { size: number }; gaussiansBuffer: ArrayBuffer;
   constructor(arrayBuffer: ArrayBuffer);
   static fromRecords(arrayBuffer: ArrayBuffer, numGaussians: number): PackedGaussians;
+  static fromFile(path: string): PackedGaussians;
 }
 export class Renderer {
   canvas: CanvasLike; interactiveCamera: InteractiveCamera; numGaussians: number; tileSize: number; numIntersections: number; numFrames: number;

@@ -104,6 +104,16 @@ class PackedGaussians {
     }
   }
 
+  // Native loader (C ABI gs_ply_load through N-API): same result as `new PackedGaussians(arrayBuffer)`,
+  // without the per-vertex JS object churn the reference warns about (index.html:16).
+  static fromFile(path) {
+    const { loadNative } = require('./renderer');
+    const r = loadNative().loadPly(path);
+    const pg = PackedGaussians.fromRecords(r.records, r.n);
+    pg.sphericalHarmonicsDegree = r.degree;
+    return pg;
+  }
+
   // Builds a PackedGaussians straight from packed 320-byte records (synthetic scenes, tests).
   static fromRecords(arrayBuffer, numGaussians) {
     const pg = Object.create(PackedGaussians.prototype);

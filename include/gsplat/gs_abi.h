@@ -123,6 +123,12 @@ int32_t gs_destroy(gs_ctx* ctx);
  * PackedGaussians.gaussiansBuffer (ply.ts:204-220), n records of 320 B, host memory.  The records
  * are re-laid-out on the device; the caller's buffer is not referenced after return. */
 int32_t gs_upload_splats(gs_ctx* ctx, const void* aos320, uint64_t n);
+/* Native PackedGaussians (ply.ts:162-228): parses a binary little-endian 3DGS .ply with the reference's header and
+ * property rules and returns n packed 320-byte records (malloc'ed; release with gs_ply_free).  sh_degree may be NULL. */
+int32_t gs_ply_load(const char* path, void** records, uint64_t* n, int32_t* sh_degree);
+void gs_ply_free(void* records);
+/* gs_ply_load + gs_upload_splats. */
+int32_t gs_upload_ply(gs_ctx* ctx, const char* path, uint64_t* n);
 /* Same, from a device pointer (no PCIe copy). */
 int32_t gs_upload_splats_device(gs_ctx* ctx, const void* d_aos320, uint64_t n);
 

@@ -26,6 +26,10 @@ async function main() {
     const pg = new g.PackedGaussians(buf);
     fs.writeFileSync(process.argv[4], Buffer.from(pg.gaussiansBuffer));
     console.log(JSON.stringify({ n: pg.numGaussians, degree: pg.sphericalHarmonicsDegree, size: pg.gaussianArrayLayout.size, nSh: pg.nShCoeffs }));
+  } else if (cmd === 'plynative') {
+    const pg = g.PackedGaussians.fromFile(process.argv[3]);
+    fs.writeFileSync(process.argv[4], Buffer.from(pg.gaussiansBuffer));
+    console.log(JSON.stringify({ n: pg.numGaussians, degree: pg.sphericalHarmonicsDegree, size: pg.gaussianArrayLayout.size }));
   } else if (cmd === 'render') {
     // render <records.bin> <n> <W> <H> <tile> <uniforms.bin> <out.rgba>
     const rec = fs.readFileSync(process.argv[3]);

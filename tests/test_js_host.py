@@ -84,6 +84,30 @@ def test_ply_loader_packs_reference_layout(tmp_path, degree, uchar):
         for i in range(K):
             np.testing.assert_array_equal(rec[:, 16 + 4 * (i + 1) + c], col["f_rest_%d" % (c * K + i)])
     assert not rec[:, 16 + 4 * (K + 1):].any() and not rec[:, 3].any() and not rec[:, 13:16].any()
+    # the native loader (C ABI gs_ply_load), directly and through N-API, packs the same bytes
+    from gsplat import _abi
+    nat, deg = _abi.load_ply(ply)
+    assert deg == degree
+    np.testing.assert_array_equal(nat.view(np.uint32), rec.view(np.uint32))
+    out2 = str(tmp_path / "rec2.bin")
+    info2 = _node("plynative", ply, out2)
+    assert info2["n"] == n and info2["degree"] == degree
+    np.testing.assert_array_equal(np.fromfile(out2, dtype=np.uint32), rec.view(np.uint32).reshape(-1))
+
+
+def test_native_ply_loader_errors(tmp_path):
+    from gsplat import _abi
+    with pytest.raises(_abi.GsError):
+        _abi.load_ply(str(tmp_path / "missing.ply"))
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 1\nproperty float x\n")
+    with pytest.raises(_abi.GsError):
+        _abi.load_ply(str(bad))  # no end_header
+    props, _ = _write_ply(str(tmp_path / "d3.ply"), 4, 3)
+    raw = (tmp_path / "d3.ply").read_bytes()
+    (tmp_path / "trunc.ply").write_bytes(raw[:-10])
+    with pytest.raises(_abi.GsError):
+        _abi.load_ply(str(tmp_path / "trunc.ply"))
 
 
 @pytest.mark.gpu
