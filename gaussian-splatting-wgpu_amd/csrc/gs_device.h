@@ -45,6 +45,7 @@ struct GsControl {
 
 struct GsScene {
     const float* px; const float* py; const float* pz; // f32[N] each: all the cull reads
+    const float* smax; // f32[N]: largest log-scale of the gaussian (only read by tile-column slabs: conservative radius)
     const float4* rec; // 256-byte record per gaussian, 16 x f32x4:
                        //   [0] log-scale xyz, opacity logit   [1] rot r,x,y,z   [2..13] 48 SH floats (coefficient-major RGB)
                        //   [14..15] padding (keeps every record on two 128-byte lines)

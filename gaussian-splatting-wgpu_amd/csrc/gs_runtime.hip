@@ -221,11 +221,12 @@ static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     c->frame.n = (uint32_t)n;
     c->have_frame = false;
     const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and the records 256-byte aligned
-    const size_t bytes = np * 3 * 4 + (size_t)n * 256;
+    const size_t bytes = np * 4 * 4 + (size_t)n * 256;
     HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
     char* p = (char*)c->scene_mem;
     GsScene& s = c->scene;
     s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
+    s.smax = (float*)p; p += np * 4;
     s.rec = (float4*)p;
     HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));

@@ -23,7 +23,7 @@
 // ---- upload: 320-byte AoS (ply.ts:190-198) -> position planes + 256-byte records ------------------
 // One thread per (gaussian, 16-byte column of the source record); runs once per scene.
 __global__ __launch_bounds__(256) void gs_repack_kernel(const float4* __restrict__ aos, uint32_t n, float* px, float* py,
-                                                         float* pz, float* rec) {
+                                                         float* pz, float* smax, float* rec) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t total = (uint64_t)n * 20; // 20 float4 per source record
     if (t >= total) return;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void gs_repack_kernel(const float4* __restrict
     const float4 v = aos[t];
     float* r = rec + (uint64_t)g * 64;
     if (c == 0) { px[g] = v.x; py[g] = v.y; pz[g] = v.z; }
-    else if (c == 1) { r[0] = v.x; r[1] = v.y; r[2] = v.z; }
+    else if (c == 1) { r[0] = v.x; r[1] = v.y; r[2] = v.z; smax[g] = __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z)); }
     else if (c == 2) { r[4] = v.x; r[5] = v.y; r[6] = v.z; r[7] = v.w; }
     else if (c == 3) { r[3] = v.x; }
     else {
@@ -104,6 +104,25 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniform
             const float ndx = ph[0] * pw, ndy = ph[1] * pw;
             m4_mulv(u.view, x, y, z, pv);
             vis[k] = !((pv[2] <= 0.2f) || (ndx <= -1.1f || ndx >= 1.1f || ndy <= -1.1f || ndy >= 1.1f));
+            if (vis[k] && !f.full) {
+                // Tile-column slab: drop the gaussian here, before its record is touched, if even a conservative
+                // bound of its screen radius cannot reach this rank's columns.  lambda_max(cov2d) <= |J|_F^2 * s_max^2
+                // (W is orthonormal), |J|_F^2 <= (fx/z)^2 (1+limx^2) + (fy/z)^2 (1+limy^2) after the clamp of :180-186,
+                // and lambda_1 <= (a+c) + sqrt(0.1) <= 2*lambda_max(cov) + 0.92; margins cover the f32 rounding.
+                const float sm = __expf(s.smax[i]) * u.scale_modifier * 1.001f;
+                const float limx = 1.3f * u.tan_fovx, limy = 1.3f * u.tan_fovy;
+                const float iz = 1.0f / pv[2];
+                const float jf2 = (u.focal_x * iz) * (u.focal_x * iz) * (1.0f + limx * limx) + (u.focal_y * iz) * (u.focal_y * iz) * (1.0f + limy * limy);
+                const float rb = 3.0f * __builtin_sqrtf(2.0f * jf2 * sm * sm + 0.92f) * 1.001f + 2.0f;
+                const float pxs = ((ndx * 0.5f) + 0.5f) * (float)f.width;
+                const float ts = (float)f.tile_size;
+                // instance columns lie in [floor(lo/ts), floor(hi/ts)] CLAMPED to [0, ntx] (getRect, :305-313): a splat
+                // entirely left of the screen still lands in column 0, one entirely right of it in column ntx (alias)
+                const float lo = pxs - rb, hi = pxs + rb;
+                const bool reach = (lo < (float)f.col1 * ts) && (f.col0 == 0u || hi >= (float)f.col0 * ts);
+                const bool alias = (f.col0 == 0u) && (hi >= (float)f.ntx * ts); // column ntx aliases to column 0
+                if (!(reach || alias) && (rb == rb)) { vis[k] = false; }
+            }
             if (!vis[k]) tile_counts[i] = 0u;
         }
         bal[k] = __ballot(vis[k]);
@@ -259,7 +278,7 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
     const uint32_t blocks = (uint32_t)((total + 255) / 256);
     if (!blocks) return;
     hipLaunchKernelGGL(gs_repack_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)d_aos, n, (float*)s.px, (float*)s.py,
-                       (float*)s.pz, (float*)s.rec);
+                       (float*)s.pz, (float*)s.smax, (float*)s.rec);
 }
 void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                           hipStream_t st) {

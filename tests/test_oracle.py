@@ -217,3 +217,22 @@ def test_golden_vectors(oracle, path):
     np.testing.assert_array_equal(r["ranges"], g["ranges"])
     np.testing.assert_array_equal(r["rgba8"], g["rgba8"])
     assert _sha(r["rgbf"]) == str(g["rgbf_sha256"])
+
+
+def test_offscreen_splats_clamp_into_edge_columns(oracle):
+    """getRect (process_gaussians.wgsl:305-313) clamps tile columns to [0, ntx]: a splat that passes the NDC cull
+    (|x| < 1.1) but lies entirely left of the canvas still gets an instance in column 0, one entirely right of it
+    lands in column ntx, which aliases to column 0 of the next row -- both belong to the slab that owns column 0."""
+    W, H = 320, 160
+    cam = _front_camera(W, H, 320.0)
+    u = cam.uniforms(W, H)
+    z = 4.0
+    left = _one_splat((-1.05 * 0.5 * z, 0, z), np.log([0.002] * 3))   # ndc.x = -1.05 -> px = -8
+    right = _one_splat((1.05 * 0.5 * z, 0, z), np.log([0.002] * 3))   # ndc.x = +1.05 -> px = 328
+    gl, cl = oracle.preprocess(left, u, W, H)
+    gr, cr = oracle.preprocess(right, u, W, H)
+    assert cl[0] == 1 and list(gl[0, 12:16:2]) == [0, 1]
+    assert cr[0] == 1 and list(gr[0, 12:16:2]) == [20, 21]
+    for s in (left, right):
+        assert oracle.preprocess(s, u, W, H, cols=(0, 5))[1][0] == 1       # the owner of column 0 keeps it
+        assert oracle.preprocess(s, u, W, H, cols=(5, 20))[1][0] == 0      # every other slab drops it
