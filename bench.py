@@ -48,6 +48,28 @@ def algorithmic_bytes(st, W, H, T):
     }
 
 
+STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_kernel"],
+                 "sort": ["gs_sort_sweep_kernel"], "ranges": ["gs_ranges_kernel"], "blend": ["gs_blend_wave_kernel", "gs_blend_kernel"]}
+
+
+def pmc_traffic(stage, workload):
+    """HBM bytes per launch of the stage's main kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc.json,
+    collected with tools/pmc_run.sh on the same workload).  MI355X_MICROARCH.md (HBM): bytes = (FETCH_SIZE + WRITE_SIZE)
+    * 1024, and on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads, so it is doubled."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.exists(path):
+        return None, None
+    js = json.load(open(path))
+    if js.get("workload") != workload:
+        return None, None
+    for k in STAGE_KERNELS[stage]:
+        c = js["kernels"].get(k)
+        if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, {"kernel": k, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+                                                                       "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count for 16 B/lane reads)"}
+    return None, None
+
+
 def cpu_baseline(n_full, W, H, seed, sample_n):
     """Times the CPU oracle (oracle/gs_oracle.c, OpenMP) on a bounded sample of the same workload."""
     from gsplat import synth
@@ -202,8 +224,10 @@ def main():
             dom = max(st["stage_us_mean"], key=lambda k_: st["stage_us_mean"][k_])
             dus = st["stage_us_mean"][dom]
             ach = ab[dom] / (dus * 1e-6) / 1e9
+            traffic, tdetail = pmc_traffic(dom, cfg["name"]) if world == 1 and not args.gaussians else (None, None)
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": tdetail,
+                                "alg_bytes_per_launch": int(ab[dom]),
                                 "launch_us": round(dus, 2), "frames_timed": st["frames_timed"],
                                 "rank0_slab_only": world > 1}
             bus = st["stage_us_mean"]["blend"]
