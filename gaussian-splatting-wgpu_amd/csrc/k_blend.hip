@@ -27,6 +27,8 @@
 // Minimum over the pixel block [dxlo,dxhi] x [dylo,dyhi] (offsets g - p) of the quadratic
 // q(d) = 0.5*(cx*dx^2 + cz*dy^2) + cy*dx*dy (power = -q).  For a positive-definite conic whose centre
 // is outside the block the minimiser lies on an edge facing the centre: at most two 1-D problems.
+// (v_rcp_f32 instead of an IEEE division: q is evaluated AT the clamped point, so a 1-ulp error in the
+// minimiser only moves q by a second-order amount, far inside the caller's margin.)
 __device__ __forceinline__ float block_qmin(float cx, float cy, float cz, float dxlo, float dxhi, float dylo, float dyhi,
                                             float& mag) {
     const float X = __builtin_fminf(__builtin_fmaxf(0.0f, dxlo), dxhi); // clamp(0, lo, hi)
@@ -35,13 +37,13 @@ __device__ __forceinline__ float block_qmin(float cx, float cy, float cz, float 
     mag = 0.0f;
     if (X == 0.0f && Y == 0.0f) return 0.0f; // centre inside the block
     if (X != 0.0f) {
-        const float dy = __builtin_fminf(__builtin_fmaxf(-cy * X / cz, dylo), dyhi);
+        const float dy = __builtin_fminf(__builtin_fmaxf(-cy * X * __builtin_amdgcn_rcpf(cz), dylo), dyhi);
         const float a = 0.5f * cx * X * X, b = 0.5f * cz * dy * dy, c = cy * X * dy;
         q = a + b + c;
         mag = __builtin_fabsf(a) + __builtin_fabsf(b) + __builtin_fabsf(c);
     }
     if (Y != 0.0f) {
-        const float dx = __builtin_fminf(__builtin_fmaxf(-cy * Y / cx, dxlo), dxhi);
+        const float dx = __builtin_fminf(__builtin_fmaxf(-cy * Y * __builtin_amdgcn_rcpf(cx), dxlo), dxhi);
         const float a = 0.5f * cx * dx * dx, b = 0.5f * cz * Y * Y, c = cy * dx * Y;
         const float q2 = a + b + c;
         if (q2 < q) { q = q2; mag = __builtin_fabsf(a) + __builtin_fabsf(b) + __builtin_fabsf(c); }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
                 } else if (piece == 2u) {
                     sP2[buf][e] = make_float4(x, y, z, ww);
                     // alpha >= c255  <=>  q <= ln(255*op); +0.01 keeps the cull conservative (rounding is ~1e-6)
-                    sP0[buf][e].z = __builtin_logf(ww * 255.0f) + 0.01f;
+                    sP0[buf][e].z = __builtin_amdgcn_logf(ww * 255.0f) * 0.693147182464599609375f + 0.01f; // v_log_f32 (log2) * ln 2
                 }
             }
         }
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restri
             const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
             const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
             const float op = __uint_as_float(r2.w);
-            const float lim = __builtin_logf(op * 255.0f) + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
+            const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
             const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
