@@ -71,6 +71,7 @@ struct gs_ctx {
     uint32_t* sort_status = nullptr;            // instance sort
     uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
     uint32_t last_passes = 0;
+    uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
     GsControl* h_ctl = nullptr; // pinned
     // outputs
     uint32_t* ranges = nullptr;
@@ -322,9 +323,10 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist, st);
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
-    if (gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
-                        c->blend_ablation, st) != 0)
-        return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
+    const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
+                                        c->blend_ablation, st);
+    if (walkers < 0) return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
+    c->blend_walkers = (uint32_t)walkers;
     mark(c, 6);
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
@@ -452,6 +454,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
+        out->num_processed /= c->blend_walkers ? c->blend_walkers : 1;
         for (int k = 0; k < 64; ++k) out->num_evaluated += c->h_ctl->num_evaluated[k];
         if (c->have_events && c->frames > 0) {
             const uint64_t last = c->frames - 1;

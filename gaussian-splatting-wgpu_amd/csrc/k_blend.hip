@@ -402,6 +402,152 @@ __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quadrant variant: one single-wave workgroup per 8x8 pixel block of a 16x16 tile, each walking the
+// tile's list on its own.  Four times as many, four times shorter pipelines than the whole-tile wave
+// kernel: the dispatcher keeps refilling the SIMDs until the end of the launch instead of letting
+// the occupancy decay as the 8 160 whole-tile waves retire, and a block stops as soon as ITS 64
+// pixels are final.  The four blocks of a tile are workgroups b, b+8, b+16, b+24 (the same XCD under
+// round-robin placement) so the three extra gathers of every record are normally L2 hits; placement
+// only affects speed.
+// ------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
+                                                            const uint32_t* __restrict__ ranges, GsFrame f,
+                                                            uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
+                                                            uint32_t dbg) {
+    constexpr int TS = 16;
+    __shared__ float4 sP0[64];
+    __shared__ float4 sP1[64];
+    __shared__ float4 sP2[64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t slab_tx = f.col1 - f.col0, ntl = slab_tx * f.nty;
+    // workgroup b: group of 32 = 8 tiles x 4 quadrants; quadrant = (b / 8) % 4, tile = (b / 32) * 8 + b % 8
+    const uint32_t b = blockIdx.x;
+    const uint32_t q = (b >> 3) & 3u;
+    const uint32_t lin = (b >> 5) * 8u + (b & 7u);
+    if (lin >= ntl) return;
+    const uint32_t tx = f.col0 + lin % slab_tx, ty = lin / slab_tx;
+    const uint32_t tile = tx + ty * f.ntx;
+    const uint32_t start = tile > 0 ? ranges[tile - 1] : 0u;
+    uint32_t end = ranges[tile];
+    if (end > f.capacity) end = f.capacity;
+    const float c255 = (float)(1.0 / 255.0);
+    const float Wf = (float)f.width, Hf = (float)f.height;
+    const uint32_t bx0 = tx * TS + (q & 1u) * 8u, by0 = ty * TS + (q >> 1) * 8u;
+    const uint32_t gx = bx0 + (lane & 7), gy = by0 + (lane >> 3);
+    const float pxf = (float)gx, pyf = (float)gy, bx0f = (float)bx0, by0f = (float)by0;
+    const bool outside = !(gx < f.width && gy < f.height);
+    bool done = outside;
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    uint32_t staged = 0, evaluated = 0;
+
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    uint32_t gnext = 0;
+    auto fetch_id = [&](uint32_t bb) { gnext = (bb + lane < end) ? values[bb + lane] : 0u; };
+    auto fetch = [&](uint32_t bb, uint32_t g) {
+        if (bb + lane < end) {
+            if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
+            r0 = gdata[(uint64_t)g * 4 + 0];
+            r1 = gdata[(uint64_t)g * 4 + 1];
+            r2 = gdata[(uint64_t)g * 4 + 2];
+        }
+    };
+    if (start < end) {
+        fetch_id(start);
+        fetch(start, gnext);
+        fetch_id(start + 64);
+    }
+    for (uint32_t bb = start; bb < end; bb += 64) {
+        const uint32_t cnt = (end - bb < 64u) ? end - bb : 64u;
+        staged += cnt;
+        bool rel = false;
+        if (lane < cnt) {
+            const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
+            const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
+            const float op = __uint_as_float(r2.w);
+            const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
+            const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
+            const float dxhi = gxp - bx0f, dyhi = gyp - by0f;
+            float mag;
+            const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
+            rel = (!pd || !(qm > lim + 1.0e-5f * mag)) && !(dbg & 1u);
+            if (rel) { // only surviving entries are parked for the broadcast
+                const float L = 1.44269502162933349609375f;
+                sP0[lane] = make_float4(gxp, gyp, 0.0f, 0.0f);
+                sP1[lane] = EXACT ? make_float4(cx, cy, cz, 0.0f) : make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, 0.0f);
+                sP2[lane] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
+            }
+        }
+        const uint32_t nb = bb + 64;
+        if (nb < end) {
+            const uint32_t g = gnext;
+            fetch(nb, g);
+            fetch_id(nb + 64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long m = __ballot(rel);
+        evaluated += (uint32_t)__popcll(m);
+        while (m) {
+            const uint32_t e = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const float4 p0 = sP0[e];
+            const float4 p1 = sP1[e];
+            const float4 p2v = sP2[e];
+            const float dx = p0.x - pxf, dy = p0.y - pyf;
+            if (EXACT) {
+                const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
+                const float power = -0.5f * (t1 + t2) - t3;
+                const float alpha = wg_min(0.99f, p2v.w * gs_exp(power));
+                const float test = T * (1.0f - alpha);
+                const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
+                cr += cond * p2v.x * alpha * T;
+                cg += cond * p2v.y * alpha * T;
+                cb += cond * p2v.z * alpha * T;
+                T = cond * test + (1.0f - cond) * T;
+            } else {
+                const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
+                const float v = (p1.z * dy) * dy;
+                const float pw = __builtin_fmaf(dx, u, v); // power * log2(e)
+                const float alpha = __builtin_fminf(0.99f, p2v.w * __builtin_amdgcn_exp2f(pw));
+                const float test = __builtin_fmaf(-T, alpha, T);
+                const bool keep = (pw <= 0.0f) && (alpha >= c255) && (test >= 0.0001f);
+                const float wgt = (keep ? alpha : 0.0f) * T;
+                cr = __builtin_fmaf(p2v.x, wgt, cr);
+                cg = __builtin_fmaf(p2v.y, wgt, cg);
+                cb = __builtin_fmaf(p2v.z, wgt, cb);
+                T = keep ? test : T;
+            }
+        }
+        if (EXACT) done = outside || (T * (1.0f - c255) < 0.0001f);
+        else done = outside || (__builtin_fmaf(-T, c255, T) < 0.0001f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__ballot(!done) == 0ull) break; // this block's 64 pixels are final (exact criterion)
+    }
+    // statistics: every quadrant adds what it staged; the host divides by 4 (mean list depth consumed per tile)
+    if (lane == 0 && staged) atomicAdd(&ctl->num_processed[b & 63u], (unsigned long long)staged);
+    if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(b + 1u) & 63u], (unsigned long long)evaluated);
+    if (!outside) {
+        const float c[3] = {cr, cg, cb};
+        uint32_t px = 0xFF000000u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = c[ch];
+            v = (v != v) ? 0.0f : wg_min(wg_max(v, 0.0f), 1.0f);
+            px |= (uint32_t)__builtin_floorf(v * 255.0f + 0.5f) << (8 * ch);
+        }
+        const uint64_t o = (uint64_t)gy * f.slab_w + (gx - f.px0);
+        rgba8[o] = px;
+        if (rgbf) {
+            rgbf[o * 3 + 0] = cr;
+            rgbf[o * 3 + 1] = cg;
+            rgbf[o * 3 + 2] = cb;
+        }
+    }
+}
+
 // ---- multi-GPU presentation: slabs (rank-major, each u32[H][w_g]) -> one row-major u32[H][W] image ---
 __global__ __launch_bounds__(256) void gs_assemble_kernel(const uint32_t* __restrict__ slabs, uint32_t* __restrict__ image,
                                                            uint32_t width, uint32_t height, const uint32_t* __restrict__ px_bounds,
@@ -426,24 +572,35 @@ static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* g
     else
         hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg);
 }
+// Returns -1 for an unsupported tile size, else the number of workgroups that walk each tile's list independently
+// (4 for the quadrant kernel, 1 otherwise): gs_stats.num_processed is the sum of their staged entries divided by it.
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
                     GsControl* ctl, bool exact, uint32_t ablation, hipStream_t st) {
     const uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
     const dim3 grid(f.col1 - f.col0, f.nty);
-    if (grid.x == 0 || grid.y == 0) return 0;
+    if (grid.x == 0 || grid.y == 0) return 1;
     const uint4* g = (const uint4*)gdata;
     switch (f.tile_size) {
-    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
+    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1;
     case 16: {
         // ablation bit 3 forces the 4-wave kernel, bit 4 the single-wave kernel; default: whole-tile waves once
         // the launch has >= 4 tiles per SIMD (1024 SIMDs), else the 4-wave kernel (slabs, small canvases)
-        const bool wave = (dbg & 16u) ? true : (dbg & 8u) ? false : ((uint64_t)grid.x * grid.y >= 4096u);
-        if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0; }
+        // default: one single-wave workgroup per 8x8 quadrant; ablation bits force the others
+        // (8 = 4-wave workgroup per tile, 16 = one wave per whole tile)
+        const bool wave = (dbg & 16u) != 0;
+        if (!(dbg & (8u | 16u))) {
+            const uint32_t nt = grid.x * grid.y;
+            const uint32_t nblk = ((nt + 7) / 8) * 32;
+            if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
+            else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
+            return 4;
+        }
+        if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; }
         if (exact) hipLaunchKernelGGL((gs_blend_wave_kernel<true>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
         else hipLaunchKernelGGL((gs_blend_wave_kernel<false>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
         return 0;
     }
-    case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 0;
+    case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1;
     default: return -1;
     }
 }

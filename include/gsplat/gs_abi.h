@@ -153,7 +153,9 @@ int32_t gs_read_buffer(gs_ctx* ctx, int32_t which, void* dst, uint64_t size, uin
 int32_t gs_device_ptr(gs_ctx* ctx, int32_t which, void** d_ptr);
 int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 /* Tuning / profiling knobs. */
-#define GS_OPT_BLEND_ABLATION 1  /* PROFILING ONLY, breaks the image: bit0 = skip the per-pixel loop, bit1 = gather from a cache-resident window */
+#define GS_OPT_BLEND_ABLATION 1  /* bits 0-2 PROFILING ONLY, break the image (1 skip the pixel loop, 2 gather from a cache-resident window,
+                                    4 skip cull+loop); bits 3/4 pick another tile-16 blend kernel with identical results (8 = four-wave
+                                    workgroup per tile, 16 = one wave per whole tile; default = one wave per 8x8 quadrant)          */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
 #define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
 #define GS_OPT_EMIT_ORDER 4      /* 1 (default): the reference's gaussian-index emission order + sort by the full key (3-4 radix

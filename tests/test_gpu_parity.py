@@ -98,7 +98,7 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
-@pytest.mark.parametrize("variant", [8, 16])  # GS_OPT_BLEND_ABLATION bits: 8 = force the 4-wave kernel, 16 = force the whole-tile-wave kernel
+@pytest.mark.parametrize("variant", [0, 8, 16])  # GS_OPT_BLEND_ABLATION: 0 = default (quadrant waves), 8 = 4-wave workgroup per tile, 16 = whole-tile wave
 @pytest.mark.parametrize("exact", [True, False])
 def test_blend_kernel_variants(oracle, variant, exact):
     from gsplat import _abi
