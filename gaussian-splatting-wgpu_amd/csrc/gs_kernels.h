@@ -18,6 +18,6 @@ void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t*
                     const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
                     uint32_t grid, hipStream_t st, uint32_t** out_keys, uint32_t** out_vals);
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, bool exact, uint32_t ablation, hipStream_t st);
+                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, hipStream_t st);
 void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t height, const uint32_t* d_px_bounds, uint32_t n_slabs,
                         uint64_t slab_stride_px, hipStream_t st);

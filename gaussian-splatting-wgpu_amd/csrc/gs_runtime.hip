@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/gsplat/gs_abi.h"
 #include "gs_kernels.h"
@@ -67,6 +68,7 @@ struct gs_ctx {
     size_t ctl_bytes = 0;
     GsControl* ctl = nullptr;
     unsigned long long* scan_status = nullptr;  // [2][scan blocks]
+    uint32_t* tile_depth = nullptr;             // blend statistic: deepest staged entry per tile (quadrant kernel)
     uint32_t* gsort_status = nullptr;           // gaussian-level sort by depth bucket
     uint32_t* sort_status = nullptr;            // instance sort
     uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
@@ -124,12 +126,14 @@ static int32_t alloc_kv(gs_ctx* c, uint64_t capacity) {
     const size_t scan_sz = 2 * scan_one;
     const size_t gsort_sz = (size_t)2 * gs_sort_tiles(c->n ? c->n : 1) * 256 * 4;
     const size_t sort_sz = (size_t)std::max(c->passes, c->tile_passes) * gs_sort_tiles(capacity) * 256 * 4;
-    c->ctl_bytes = ctl_sz + scan_sz + gsort_sz + sort_sz;
+    const size_t depth_sz = ((size_t)c->T * 4 + 255) & ~(size_t)255;
+    c->ctl_bytes = ctl_sz + depth_sz + scan_sz + gsort_sz + sort_sz;
     HIP_TRY(hipMalloc(&c->ctl_mem, c->ctl_bytes));
     c->ctl = (GsControl*)c->ctl_mem;
-    c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz);
-    c->gsort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + scan_sz);
-    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + scan_sz + gsort_sz);
+    c->tile_depth = (uint32_t*)((char*)c->ctl_mem + ctl_sz);
+    c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz + depth_sz);
+    c->gsort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz);
+    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz + gsort_sz);
     c->capacity = capacity;
     c->frame.capacity = (uint32_t)capacity;
     return GS_OK;
@@ -323,7 +327,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist, st);
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
-    const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
+    const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, c->tile_depth, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
                                         c->blend_ablation, st);
     if (walkers < 0) return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
     c->blend_walkers = (uint32_t)walkers;
@@ -454,7 +458,11 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
-        out->num_processed /= c->blend_walkers ? c->blend_walkers : 1;
+        if (c->blend_walkers == 4) { // quadrant kernel: sum over tiles of the deepest walker
+            std::vector<uint32_t> depth(c->T);
+            if (hipMemcpy(depth.data(), c->tile_depth, (size_t)c->T * 4, hipMemcpyDeviceToHost) == hipSuccess)
+                for (uint32_t v : depth) out->num_processed += v;
+        }
         for (int k = 0; k < 64; ++k) out->num_evaluated += c->h_ctl->num_evaluated[k];
         if (c->have_events && c->frames > 0) {
             const uint64_t last = c->frames - 1;

@@ -415,7 +415,7 @@ template <bool EXACT>
 __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                             const uint32_t* __restrict__ ranges, GsFrame f,
                                                             uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
-                                                            uint32_t dbg) {
+                                                            uint32_t* __restrict__ tile_depth, uint32_t dbg) {
     constexpr int TS = 16;
     __shared__ float4 sP0[64];
     __shared__ float4 sP1[64];
@@ -526,8 +526,9 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (__ballot(!done) == 0ull) break; // this block's 64 pixels are final (exact criterion)
     }
-    // statistics: every quadrant adds what it staged; the host divides by 4 (mean list depth consumed per tile)
-    if (lane == 0 && staged) atomicAdd(&ctl->num_processed[b & 63u], (unsigned long long)staged);
+    // statistics: a tile's "staged before early exit" depth is the deepest any of its quadrants went
+    // (tile_depth[] is zeroed with the control block; the host sums it)
+    if (lane == 0 && staged) atomicMax(&tile_depth[lin], staged);
     if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(b + 1u) & 63u], (unsigned long long)evaluated);
     if (!outside) {
         const float c[3] = {cr, cg, cb};
@@ -572,10 +573,10 @@ static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* g
     else
         hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg);
 }
-// Returns -1 for an unsupported tile size, else the number of workgroups that walk each tile's list independently
-// (4 for the quadrant kernel, 1 otherwise): gs_stats.num_processed is the sum of their staged entries divided by it.
+// Returns -1 for an unsupported tile size, 4 when the quadrant kernel ran (gs_stats.num_processed is then the sum of
+// tile_depth[], the per-tile maximum over its four independent walkers), 1 otherwise (ctl->num_processed).
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, bool exact, uint32_t ablation, hipStream_t st) {
+                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, hipStream_t st) {
     const uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
     const dim3 grid(f.col1 - f.col0, f.nty);
     if (grid.x == 0 || grid.y == 0) return 1;
@@ -591,8 +592,8 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
         if (!(dbg & (8u | 16u))) {
             const uint32_t nt = grid.x * grid.y;
             const uint32_t nblk = ((nt + 7) / 8) * 32;
-            if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
-            else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
+            if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+            else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
             return 4;
         }
         if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; }
