@@ -31,7 +31,7 @@ struct GsControl {
     uint32_t scan_ticket[2];  // dynamic block ids: [0] tile-count scan in index order, [1] in depth order
     uint32_t sort_ticket[4];  // dynamic tile ids, one per radix pass of the instance sort
     uint32_t gsort_ticket[2]; // ... of the gaussian-level sort by depth bucket
-    uint32_t pad1;
+    uint32_t pe_ticket;       // ... of the fused projection+scan+emission kernel
     uint32_t fault;           // set when a bounded spin gives up
     uint32_t overflow;        // set when I exceeds capacity
     uint32_t num_intersections; // I (written by the scan's last block)

@@ -5,6 +5,9 @@
 void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream_t st);
 void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                           hipStream_t st);
+uint32_t gs_project_emit_blocks(uint32_t n);
+void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, uint32_t* keys,
+                            uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st);
 uint32_t gs_scan_blocks(uint32_t n);
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
                     uint32_t* vkey, uint32_t* vval, unsigned long long* status, uint32_t* ticket, GsControl* ctl, uint32_t write_totals,

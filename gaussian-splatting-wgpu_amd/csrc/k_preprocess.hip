@@ -81,13 +81,37 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
 }
 
 #define PRE_G 512 // gaussians per workgroup
+#define PE_AGG (1ull << 62)
+#define PE_PREFIX (2ull << 62)
+#define PE_MASK (3ull << 62)
 
+// FUSED = false: projection only (tile counts + GaussianData); the scan and the key emission are separate kernels
+//                (gs_render_debug, which must expose the reference's intermediate buffers, and the experimental
+//                depth-ordered pipeline).
+// FUSED = true : projection, the exclusive scan of the tile counts AND the (key,value) emission in ONE pass: a workgroup
+//                scans its 512 counts in LDS, gets its base offset by decoupled look-back over one 8-byte
+//                {flag, visible, sum} granule per workgroup (ticket-ordered, so it only waits on workgroups that have
+//                started) and expands its instances with coalesced stores straight from the rects it still holds in
+//                LDS.  Emission order is the reference's (gaussian index, y, x); offsets/rects never travel through HBM.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
-                                                             uint32_t* __restrict__ tile_counts) {
+                                                             uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ values, unsigned long long* status,
+                                                             uint32_t* ticket, GsControl* ctl) {
     __shared__ uint32_t s_ids[PRE_G];
     __shared__ uint32_t s_cnt[2][4];
+    __shared__ uint32_t s_ecnt[FUSED ? PRE_G : 1]; // tile count, then exclusive prefix, of the v-th survivor
+    __shared__ uint32_t s_erow[FUSED ? PRE_G : 1]; // xa | wmain<<16 | alias<<31
+    __shared__ uint32_t s_eyb[FUSED ? PRE_G : 1];  // y0 | bucket<<16
+    __shared__ uint32_t s_misc[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t base = blockIdx.x * PRE_G;
+    uint32_t bid = blockIdx.x;
+    if (FUSED) { // dynamic workgroup id: a workgroup only ever waits on lower tickets, which are already running
+        if (tid == 0) s_misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        bid = s_misc[0];
+    }
+    const uint32_t base = bid * PRE_G;
 
     // ---- phase 1: in_frustum (:108-125) on the position planes, survivors compacted ----
     bool vis[2];
@@ -212,16 +236,18 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniform
             rminy = (uint32_t)wg_mini(nty, wg_maxi(0, f2i_sat(pys - radius) / ts));
             rmaxx = (uint32_t)(wg_mini(ntx, wg_maxi(0, f2i_sat(pxs + radius) / ts)) + 1);
             rmaxy = (uint32_t)(wg_mini(nty, wg_maxi(0, f2i_sat(pys + radius) / ts)) + 1);
-            if (f.full) {
-                count = (rmaxy - rminy) * (rmaxx - rminx); // :86
-            } else {
-                uint32_t xa, wmain, alias;
-                slab_cols(rminx, rmaxx, f, xa, wmain, alias);
-                count = (rmaxy - rminy) * (wmain + alias);
-            }
+            uint32_t xa, wmain, alias; // columns of the rect inside this ctx's slab (the whole rect when f.full)
+            slab_cols(rminx, rmaxx, f, xa, wmain, alias);
+            count = f.full ? (rmaxy - rminy) * (rmaxx - rminx) /* :86 */ : (rmaxy - rminy) * (wmain + alias);
+            if (FUSED) s_erow[v] = xa | (wmain << 16) | (alias << 31);
         }
         // low 22 bits: tile count; high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
-        tile_counts[i] = count ? (count | (f2u_sat(wg_min(50.0f * pv[2], 999.0f)) << GS_COUNT_BITS)) : 0u;
+        const uint32_t bucket = f2u_sat(wg_min(50.0f * pv[2], 999.0f));
+        tile_counts[i] = count ? (count | (bucket << GS_COUNT_BITS)) : 0u;
+        if (FUSED) {
+            s_ecnt[v] = count;
+            s_eyb[v] = rminy | (bucket << 16);
+        }
         if (count == 0) continue; // det == 0, or (slab mode) no instance in this rank's tile columns
 
         // ---- phase 3: colour (:240-280) and opacity (:282-294) ----
@@ -270,6 +296,91 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniform
         o4[2] = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[1]), __float_as_uint(col[2]), __float_as_uint(opacity));
         o4[3] = make_uint4(rminx, rminy, rmaxx, rmaxy);
     }
+    if (!FUSED) return;
+
+    // ---- scan of the workgroup's counts (survivor order = gaussian index order), look-back, emission ----
+    __syncthreads();
+    const uint32_t nblocks = (f.n + PRE_G - 1) / PRE_G;
+    const uint32_t c0 = (2 * tid < nvis) ? s_ecnt[2 * tid] : 0u, c1 = (2 * tid + 1 < nvis) ? s_ecnt[2 * tid + 1] : 0u;
+    const uint32_t pair = c0 + c1, pair_nz = (c0 != 0u) + (c1 != 0u);
+    const uint32_t incl = wave_incl_scan(pair, lane);
+    const uint32_t nzw = wave_sum(pair_nz);
+    if (lane == 63) s_misc[w] = incl;
+    if (lane == 0) s_misc[4 + w] = nzw;
+    __syncthreads();
+    uint32_t wave_excl = 0, block_total = 0, block_nz = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < (int)w) wave_excl += s_misc[k];
+        block_total += s_misc[k];
+        block_nz += s_misc[4 + k];
+    }
+    const uint32_t ex0 = wave_excl + incl - pair;
+    __syncthreads(); // s_misc is reused below; every thread has read its s_ecnt pair
+    if (2 * tid < nvis) s_ecnt[2 * tid] = ex0;
+    if (2 * tid + 1 < nvis) s_ecnt[2 * tid + 1] = ex0 + c0;
+    if (w == 0) {
+        const unsigned long long mine = ((unsigned long long)block_nz << 32) | (unsigned long long)block_total;
+        if (lane == 0) st_agent64(&status[bid], (bid == 0 ? PE_PREFIX : PE_AGG) | mine);
+        uint32_t excl = 0, excl_nz = 0;
+        if (bid > 0) {
+            int look = (int)bid - 1;
+            for (;;) {
+                const int idx = look - (int)lane;
+                unsigned long long sv = PE_PREFIX; // lanes before workgroup 0 contribute a zero prefix
+                if (idx >= 0) {
+                    uint32_t spins = 0;
+                    do {
+                        sv = ld_agent64(&status[idx]);
+                        if ((sv & PE_MASK) != 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    } while (++spins < GS_SPIN_LIMIT);
+                    if ((sv & PE_MASK) == 0) { ctl->fault = 1u; sv = PE_PREFIX; } // gave up: report, terminate the chain
+                }
+                const unsigned long long pmask = __ballot((sv & PE_MASK) == PE_PREFIX);
+                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+                excl += wave_sum((lane <= first) ? (uint32_t)sv : 0u);
+                excl_nz += wave_sum((lane <= first) ? (uint32_t)((sv & ~PE_MASK) >> 32) : 0u);
+                if (pmask) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            if (bid > 0)
+                st_agent64(&status[bid], PE_PREFIX | ((unsigned long long)(excl_nz + block_nz) << 32) | (unsigned long long)(excl + block_total));
+            s_misc[0] = excl;
+            if (bid == nblocks - 1) {
+                ctl->num_visible = excl_nz + block_nz;
+                ctl->num_intersections = excl + block_total;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t base_off = s_misc[0];
+    // instance e of the workgroup belongs to the last survivor v with prefix[v] <= e (zero-count survivors share
+    // their successor's prefix and are skipped by taking the last); y outer, x inner as write_tile_ids.wgsl:26-33
+    for (uint32_t e = tid; e < block_total; e += 256) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 256; step >= 1; step >>= 1) {
+            const uint32_t mid = lo + step;
+            if (mid < nvis && s_ecnt[mid] <= e) lo = mid;
+        }
+        const uint32_t local = e - s_ecnt[lo];
+        const uint32_t r = s_erow[lo], y_b = s_eyb[lo];
+        const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
+        const uint32_t wtot = wmain + alias;
+        const uint32_t yy = local / wtot, xx = local - yy * wtot;
+        const uint32_t x = (xx < wmain) ? xa + xx : f.ntx;
+        const uint32_t y = (y_b & 0xFFFFu) + yy;
+        const uint32_t dst = base_off + e;
+        if (dst < f.capacity) {
+            keys[dst] = (y * f.ntx + x) * 1000u + (y_b >> 16);
+            values[dst] = base + s_ids[lo];
+        } else {
+            ctl->overflow = 1u;
+        }
+    }
 }
 
 // ---- host launchers --------------------------------------------------------------------------------
@@ -284,5 +395,15 @@ void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& 
                           hipStream_t st) {
     const uint32_t blocks = (f.n + PRE_G - 1) / PRE_G;
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_preprocess_kernel, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts);
+    hipLaunchKernelGGL(gs_preprocess_kernel<false>, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr);
+}
+uint32_t gs_project_emit_blocks(uint32_t n) { return (n + PRE_G - 1) / PRE_G; }
+// projection + scan + emission in one launch; status: gs_project_emit_blocks(n) zeroed 8-byte words, ticket: one zeroed word
+void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, uint32_t* keys,
+                            uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st) {
+    const uint32_t blocks = gs_project_emit_blocks(f.n);
+    if (!blocks) return;
+    hipLaunchKernelGGL(gs_preprocess_kernel<true>, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, keys, values, status,
+                       ticket, ctl);
 }

@@ -163,6 +163,8 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     measured slower end to end in round 1: the gaussian-level pre-sort and the unbalanced
                                     emission cost more than the saved sweep).  Sorted keys/values, ranges and image are
                                     identical either way.                                                                */
+#define GS_OPT_UNFUSED 5         /* 1 (default): projection, scan and emission are three launches; 0: experimental single fused launch
+                                    (identical results; measured slower in round 1)                                              */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
 /* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
 int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);

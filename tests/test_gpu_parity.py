@@ -77,6 +77,11 @@ def test_frame_exact_mode(oracle, n, W, H, ts):
     r.render_uniforms(u)  # the product path (no debug copies, no gdata clear)
     r.wait()
     _check_stages(r, ref, exact_image=True, debug=False)
+    r.set_option(_abi.GS_OPT_UNFUSED, 0)  # experimental: projection + scan + emission fused in one launch
+    r.render_uniforms(u)
+    r.wait()
+    _check_stages(r, ref, exact_image=True, debug=False)
+    r.set_option(_abi.GS_OPT_UNFUSED, 1)
     r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)  # experimental: depth-ordered emission, tile-only instance sort
     r.render_uniforms(u)
     r.wait()
