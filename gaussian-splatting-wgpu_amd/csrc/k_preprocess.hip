@@ -81,6 +81,9 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
 }
 
 #define PRE_G 512 // gaussians per workgroup
+#ifndef PRE_WAVES
+#define PRE_WAVES 4 // waves per SIMD the register allocator must leave room for
+#endif
 #define PE_AGG (1ull << 62)
 #define PE_PREFIX (2ull << 62)
 #define PE_MASK (3ull << 62)
@@ -94,7 +97,7 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
 //                started) and expands its instances with coalesced stores straight from the rects it still holds in
 //                LDS.  Emission order is the reference's (gaussian index, y, x); offsets/rects never travel through HBM.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
+__global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
                                                              uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ keys,
                                                              uint32_t* __restrict__ values, unsigned long long* status,
                                                              uint32_t* ticket, GsControl* ctl) {
