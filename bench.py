@@ -38,9 +38,12 @@ CONFIGS = {
 def algorithmic_bytes(st, W, H, T):
     """SURVEY.md 8(d) per-frame algorithmic bytes, per stage."""
     N, Nv, I, Ip, p = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"]
+    # depth-ordered pipeline: the scan stage also compacts the visible gaussians (8 B), sorts them by depth bucket
+    # (2 digits: (4 + 16*2) B) and scans their counts in that order (12 B), all per VISIBLE gaussian
+    extra = (8 + 36 + 12) * Nv if st.get("depth_ordered") else 0
     return {
         "preprocess": 12 * (N - Nv) + 236 * Nv + 4 * N + 56 * Nv,
-        "scan": 8 * N,
+        "scan": 8 * N + extra,
         "emit": 24 * Nv + 8 * I,
         "sort": (4 + 16 * p) * I,
         "ranges": 4 * I + 4 * T,
@@ -102,7 +105,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count")
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--blend-ablation", type=int, default=0, help="profiling only: see GS_OPT_BLEND_ABLATION")
-    ap.add_argument("--emit-order", type=int, default=-1, help="GS_OPT_EMIT_ORDER override (0 depth-ordered, 1 index order)")
+    ap.add_argument("--emit-order", type=int, default=-1, help="GS_OPT_EMIT_ORDER override (0 depth-ordered, 1 index order, 2 auto = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
@@ -213,7 +216,8 @@ def main():
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
                        "parallelism": "tile-column slabs x%d + all-gather" % world if world > 1 else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
-                       "sort_passes": st["sort_passes"], "camera": "64-step orbit, moved every frame"},
+                       "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),
+                       "camera": "64-step orbit, moved every frame"},
         }
         if not args.no_timing and st["frames_timed"]:
             ab = algorithmic_bytes(st, W, H, T)

@@ -10,8 +10,12 @@ void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame
                             uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st);
 uint32_t gs_scan_blocks(uint32_t n);
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
-                    uint32_t* vkey, uint32_t* vval, unsigned long long* status, uint32_t* ticket, GsControl* ctl, uint32_t write_totals,
-                    hipStream_t st);
+                    uint32_t* vkey, uint32_t* vval, uint32_t* chunk_table, uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
+                    GsControl* ctl, uint32_t write_totals, hipStream_t st);
+uint64_t gs_emit_chunks(uint64_t capacity);
+void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
+                             const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
+                             hipStream_t st);
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,

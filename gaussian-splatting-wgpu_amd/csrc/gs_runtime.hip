@@ -47,7 +47,8 @@ struct gs_ctx {
     GsFrame frame{};
     uint32_t T = 0, passes = 0, key_bits = 0; // passes: 8-bit digits of the full key (reference-order pipeline)
     uint32_t tile_passes = 0, tile_bits = 0;  // digits of key/1000 (depth-ordered pipeline)
-    bool index_order = true;                  // GS_OPT_EMIT_ORDER: emit in gaussian-index order like the reference (default)
+    int emit_order = 2;                       // GS_OPT_EMIT_ORDER: 0 depth-bucket order, 1 gaussian-index order (reference), 2 auto
+    bool index_order = true;                  // what the frame being enqueued uses
     bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
     uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
@@ -63,6 +64,7 @@ struct gs_ctx {
     uint64_t capacity = 0;
     uint32_t *keysA = nullptr, *valsA = nullptr, *keysB = nullptr, *valsB = nullptr;
     uint32_t *keysU = nullptr, *valsU = nullptr; // debug copies of the unsorted arrays
+    uint32_t* chunk_table = nullptr;             // balanced emission: first gaussian of every EMIT_CHUNK output slots
     uint32_t *keysS = nullptr, *valsS = nullptr; // where the sorted result of the last frame lives
     // control block + look-back status words (one allocation, one memset per frame)
     void* ctl_mem = nullptr;
@@ -74,6 +76,7 @@ struct gs_ctx {
     uint32_t* sort_status = nullptr;            // instance sort
     uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
     uint32_t last_passes = 0;
+    bool last_by_index = true;
     uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
     GsControl* h_ctl = nullptr; // pinned
     // outputs
@@ -107,8 +110,9 @@ GS_EXPORT int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
 
 static void free_kv(gs_ctx* c) {
     hipFree(c->keysA); hipFree(c->valsA); hipFree(c->keysB); hipFree(c->valsB); hipFree(c->keysU); hipFree(c->valsU);
-    hipFree(c->ctl_mem);
+    hipFree(c->ctl_mem); hipFree(c->chunk_table);
     c->keysA = c->valsA = c->keysB = c->valsB = c->keysU = c->valsU = nullptr;
+    c->chunk_table = nullptr;
     c->ctl_mem = nullptr;
 }
 
@@ -122,6 +126,7 @@ static int32_t alloc_kv(gs_ctx* c, uint64_t capacity) {
     HIP_TRY(hipMalloc((void**)&c->valsA, kb));
     HIP_TRY(hipMalloc((void**)&c->keysB, kb));
     HIP_TRY(hipMalloc((void**)&c->valsB, kb));
+    HIP_TRY(hipMalloc((void**)&c->chunk_table, (size_t)gs_emit_chunks(capacity) * 4));
     const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
     // the fused projection+scan+emission kernel has 8x more (smaller) workgroups than the stand-alone scan
     const size_t scan_one = (((size_t)gs_project_emit_blocks(c->n ? c->n : 1) + 1) * 8 + 255) & ~(size_t)255;
@@ -286,6 +291,15 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
+    if (c->emit_order == 2) {
+        // auto: the depth-ordered pipeline saves (passes - tile_passes) full sweeps of the instance arrays (16 B per
+        // instance each, ~3 TB/s) and costs ~250 us of small gaussian-level kernels: worth it on a whole canvas once the
+        // previous frame's instance count times the sweeps saved exceeds ~37 M (1080p/42 M: break-even; 4K/134 M: +30 %)
+        const uint64_t saved = c->passes > c->tile_passes ? c->passes - c->tile_passes : 0;
+        c->index_order = !(f.full && c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 37000000ull);
+    } else {
+        c->index_order = (c->emit_order == 1);
+    }
     const bool fused = !debug && c->index_order && !c->unfused;
     if (fused) {
         // experimental (GS_OPT_UNFUSED 0): projection, scan and emission in ONE launch; measured 9 % slower than the three
@@ -302,7 +316,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     if (fused) {
     } else if (by_index) {
         // the reference's order: scan counts in gaussian order, emit in gaussian order, sort by the full key
-        gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         mark(c, 2);
         gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);
     } else {
@@ -310,14 +324,14 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         // gaussian index).  Sorting the N_vis visible GAUSSIANS by bucket first (stable, 10 bits, ~16x fewer elements
         // than instances) and emitting their instances in that order leaves only the tile id for the stable instance
         // sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
-        gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         uint32_t *gk = nullptr, *gperm = nullptr;
         gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
                        c->n, 2, 5, 0, c->gsort_status, c->grid_persist, st, &gk, &gperm);
-        gs_launch_scan(c->counts, gperm, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->scan_status + scan_blocks,
+        gs_launch_scan(c->counts, gperm, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table, (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks,
                        &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
-        gs_launch_emit(c->gdata, c->counts, c->offsets, gperm, &c->ctl->num_visible, f, c->keysA, c->valsA, c->ctl, st);
+        gs_launch_emit_balanced(c->gdata, c->counts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist, st);
     }
     if (debug) {
         if (!c->keysU) {
@@ -335,6 +349,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
                        (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
     c->last_passes = by_index ? c->passes : c->tile_passes;
+    c->last_by_index = by_index;
     mark(c, 4);
     gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist, st);
     mark(c, 5);
@@ -407,7 +422,7 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
     switch (which) {
     case GS_BUF_TILE_COUNTS: *ptr = c->counts; *bytes = (uint64_t)c->n * 4; return GS_OK;
     case GS_BUF_TILE_OFFSETS:
-        if (!c->last_debug && !c->index_order) return fail(GS_ERR_NO_FRAME, "the offsets tap needs gs_render_debug (index-order scan)");
+        if (!c->last_debug) return fail(GS_ERR_NO_FRAME, "the offsets tap needs gs_render_debug (index-order scan)");
         *ptr = c->offsets; *bytes = (uint64_t)c->n * 4; return GS_OK;
     case GS_BUF_GAUSSIAN_DATA: *ptr = c->gdata; *bytes = (uint64_t)c->n * 64; return GS_OK;
     case GS_BUF_KEYS_UNSORTED:
@@ -464,8 +479,9 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
     memset(out, 0, sizeof(*out));
     out->num_gaussians = c->n;
     out->num_tiles = c->T;
-    out->sort_passes = c->last_passes ? c->last_passes : (c->index_order ? c->passes : c->tile_passes);
+    out->sort_passes = c->last_passes ? c->last_passes : c->passes;
     out->frames = c->frames;
+    out->depth_ordered = (c->have_frame && !c->last_by_index) ? 1u : 0u;
     if (c->have_frame) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
@@ -518,7 +534,7 @@ GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; return GS_OK;
-    case GS_OPT_EMIT_ORDER: c->index_order = (value != 0); return GS_OK;
+    case GS_OPT_EMIT_ORDER: if (value < 0 || value > 2) break; c->emit_order = (int)value; return GS_OK;
     case GS_OPT_UNFUSED: c->unfused = (value != 0); return GS_OK;
     default: break;
     }
@@ -727,7 +743,7 @@ GS_EXPORT int32_t gs_exclusive_scan_u32(int32_t device, uint32_t* data, uint64_t
     TRY2(hipMemset(ctl_mem, 0, ctl_sz + st_sz));
     TRY2(hipMemcpy(in, data, kb, hipMemcpyHostToDevice));
     GsControl* ctl = (GsControl*)ctl_mem;
-    gs_launch_scan(in, nullptr, nullptr, (uint32_t)n, out, nullptr, nullptr, (unsigned long long*)((char*)ctl_mem + ctl_sz),
+    gs_launch_scan(in, nullptr, nullptr, (uint32_t)n, out, nullptr, nullptr, nullptr, 0u, (unsigned long long*)((char*)ctl_mem + ctl_sz),
                    &ctl->scan_ticket[0], ctl, 1u, nullptr);
     TRY2(hipGetLastError());
     TRY2(hipDeviceSynchronize());

@@ -18,6 +18,8 @@
 // word: the count of visible gaussians rides along the same look-back (a separate atomic counter on one
 // hot word serialises at ~88 atomics/us on this chip).
 // ------------------------------------------------------------------------------------------------
+#define EMIT_CHUNK_SHIFT 10
+#define EMIT_CHUNK (1u << EMIT_CHUNK_SHIFT) // output slots one wave emits at a time in the balanced emission
 #define SCAN_ITEMS 16
 #define SCAN_TILE (256 * SCAN_ITEMS)
 #define ST_AGG (1ull << 62)
@@ -30,10 +32,13 @@
 //   n_dev    : optional device word holding the element count (then n_static is only the launch bound)
 //   offsets  : optional output, exclusive prefix of the tile counts
 //   vkey/vval: optional ordered compaction of the non-zero elements: (bucket, element index)
+//   chunk_table: optional; chunk_table[c] = the element whose instances contain output slot c*EMIT_CHUNK, which
+//              lets the balanced emission start every chunk without searching
 __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ gather,
                                                        const uint32_t* __restrict__ n_dev, uint32_t n_static,
                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ vkey,
-                                                       uint32_t* __restrict__ vval, unsigned long long* status, uint32_t* ticket,
+                                                       uint32_t* __restrict__ vval, uint32_t* __restrict__ chunk_table,
+                                                       uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
                                                        GsControl* ctl, uint32_t write_totals) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_wsum[4];
@@ -131,6 +136,18 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
                 vval[run_nz] = base + j;
                 ++run_nz;
             }
+        }
+    }
+    if (chunk_table) {
+        uint32_t r2 = run;
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) {
+            const uint32_t cnt = v[j] & GS_COUNT_MASK;
+            if (cnt) {
+                const uint32_t last = (r2 + cnt - 1u) >> EMIT_CHUNK_SHIFT;
+                for (uint32_t c = (r2 + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT; c <= last && c < chunk_cap; ++c) chunk_table[c] = base + j;
+            }
+            r2 += cnt;
         }
     }
     if (!offsets) return;
@@ -241,6 +258,88 @@ __global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Work-balanced emission for the depth-ordered pipeline.  There the gaussians arrive sorted by depth
+// bucket, so the nearest (largest on screen) ones are neighbours: giving a wave 64 consecutive gaussians
+// (as gs_emit_kernel does) hands a few waves millions of instances.  Here a wave owns EMIT_CHUNK
+// consecutive OUTPUT slots instead; chunk_table (written by the scan) names the gaussian that covers the
+// chunk's first slot, and the wave walks forward from it 64 gaussians at a time.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
+                                                                const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
+                                                                const uint32_t* __restrict__ chunk_table, GsFrame f,
+                                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ values,
+                                                                GsControl* ctl) {
+    __shared__ uint32_t s_off[4][64];
+    __shared__ uint32_t s_row[4][64]; // xa | wmain<<16 | alias<<31
+    __shared__ uint32_t s_yb[4][64];  // y0 | bucket<<16
+    __shared__ uint32_t s_gid[4][64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t nvis = ctl->num_visible;
+    uint32_t total = ctl->num_intersections;
+    if (total > f.capacity) { // the frame does not fit: flag it, emit what fits (gs_wait grows and re-renders)
+        if (tid == 0 && blockIdx.x == 0) ctl->overflow = 1u;
+        total = f.capacity;
+    }
+    const uint32_t nchunks = (total + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT;
+    for (uint32_t c = blockIdx.x * 4u + w; c < nchunks; c += gridDim.x * 4u) {
+        const uint32_t c1 = (c + 1u) * EMIT_CHUNK < total ? (c + 1u) * EMIT_CHUNK : total;
+        uint32_t e = c * EMIT_CHUNK;
+        uint32_t kbase = chunk_table[c];
+        while (e < c1 && kbase < nvis) {
+            const uint32_t k = kbase + lane;
+            uint32_t off = 0xFFFFFFFFu, row = 0, yb = 0, gid = 0, cnt = 0;
+            if (k < nvis) {
+                gid = perm[k];
+                const uint32_t packed = counts[gid];
+                cnt = packed & GS_COUNT_MASK;
+                off = offsets[k];
+                const uint4 rect = gdata[(uint64_t)gid * 4 + 3];
+                uint32_t xa, wmain, alias;
+                slab_cols_emit(rect.x, rect.z, f, xa, wmain, alias);
+                row = xa | (wmain << 16) | (alias << 31);
+                yb = rect.y | ((packed >> GS_COUNT_BITS) << 16);
+            }
+            s_off[w][lane] = off;
+            s_row[w][lane] = row;
+            s_yb[w][lane] = yb;
+            s_gid[w][lane] = gid;
+            // slots covered by this group of 64 gaussians end where its last member's instances end
+            const uint32_t endk = (k < nvis) ? off + cnt : 0u;
+            uint32_t gend = endk;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t o = __shfl_xor(gend, d, 64);
+                gend = o > gend ? o : gend;
+            }
+            const uint32_t stop = gend < c1 ? gend : c1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t x = e + lane; x < stop; x += 64) {
+                uint32_t lo = 0; // largest j with s_off[j] <= x (absent members carry 0xFFFFFFFF)
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const uint32_t mid = lo + step;
+                    if (mid < 64 && s_off[w][mid] <= x) lo = mid;
+                }
+                const uint32_t local = x - s_off[w][lo];
+                const uint32_t r = s_row[w][lo], y_b = s_yb[w][lo];
+                const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
+                const uint32_t wtot = wmain + alias;
+                const uint32_t yy = local / wtot, xx = local - yy * wtot;
+                const uint32_t px = (xx < wmain) ? xa + xx : f.ntx;
+                const uint32_t py = (y_b & 0xFFFFu) + yy;
+                keys[x] = (py * f.ntx + px) * 1000u + (y_b >> 16);
+                values[x] = s_gid[w][lo];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            e = stop;
+            kbase += 64;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ranges: ranges[t] = |{ j < I : key_j/1000 <= t }| (entries with tile >= T ignored, A.6).
 // Boundary j in [0, I] owns the tiles t with tile[j-1] <= t < tile[j]  (tile[-1] = 0 bound, tile[I] = T):
 // every tile is written exactly once, so `ranges` never needs the reference's per-frame clear.
@@ -285,12 +384,19 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restri
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
-                    uint32_t* vkey, uint32_t* vval, unsigned long long* status, uint32_t* ticket, GsControl* ctl, uint32_t write_totals,
-                    hipStream_t st) {
+                    uint32_t* vkey, uint32_t* vval, uint32_t* chunk_table, uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
+                    GsControl* ctl, uint32_t write_totals, hipStream_t st) {
     const uint32_t blocks = gs_scan_blocks(n_static);
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(256), 0, st, counts, gather, n_dev, n_static, offsets, vkey, vval, status, ticket,
-                       ctl, write_totals);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(256), 0, st, counts, gather, n_dev, n_static, offsets, vkey, vval, chunk_table,
+                       chunk_cap, status, ticket, ctl, write_totals);
+}
+uint64_t gs_emit_chunks(uint64_t capacity) { return (capacity >> EMIT_CHUNK_SHIFT) + 2; }
+void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
+                             const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(gs_emit_balanced_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, chunk_table, f, keys,
+                       values, ctl);
 }
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st) {

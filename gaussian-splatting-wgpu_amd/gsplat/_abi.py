@@ -44,7 +44,7 @@ class GsStats(ctypes.Structure):
     _fields_ = [("num_gaussians", ctypes.c_uint64), ("num_visible", ctypes.c_uint64), ("num_intersections", ctypes.c_uint64),
                 ("num_processed", ctypes.c_uint64), ("num_tiles", ctypes.c_uint32), ("sort_passes", ctypes.c_uint32),
                 ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float),
-                ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("num_evaluated", ctypes.c_uint64)]
+                ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32), ("depth_ordered", ctypes.c_uint32), ("num_evaluated", ctypes.c_uint64)]
 
 
 class GsError(RuntimeError):

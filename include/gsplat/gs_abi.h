@@ -90,7 +90,7 @@ typedef struct gs_stats {
     float stage_us_mean[GS_STAGE_COUNT]; /* mean over the frames since GS_OPT_RESET_TIMING (at most the last 256) */
     float frame_us_mean;
     uint32_t frames_timed;        /* frames the means cover                                    */
-    uint32_t pad_;
+    uint32_t depth_ordered;       /* 1 if the last frame used the depth-ordered pipeline (GS_OPT_EMIT_ORDER)   */
     uint64_t num_evaluated;       /* blend: (8x8 pixel block, entry) pairs evaluated after the block cull */
 } gs_stats;
 
@@ -158,11 +158,12 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     workgroup per tile, 16 = one wave per whole tile; default = one wave per 8x8 quadrant)          */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
 #define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
-#define GS_OPT_EMIT_ORDER 4      /* 1 (default): the reference's gaussian-index emission order + sort by the full key (3-4 radix
-                                    digits); 0: experimental depth-bucket emission order + tile-only instance sort (2 digits;
-                                    measured slower end to end in round 1: the gaussian-level pre-sort and the unbalanced
-                                    emission cost more than the saved sweep).  Sorted keys/values, ranges and image are
-                                    identical either way.                                                                */
+#define GS_OPT_EMIT_ORDER 4      /* 1: the reference's gaussian-index emission order + sort by the full key (3-4 radix digits);
+                                    0: depth-ordered pipeline: sort the visible GAUSSIANS by depth bucket, emit their instances
+                                    in that order (work-balanced), sort the instances by tile only (2 digits);
+                                    2 (default): choose per frame from the previous frame's instance count (whole canvas and
+                                    many instances -> 0, slabs and small scenes -> 1).  Sorted keys/values, ranges and image
+                                    are identical in every mode.                                                          */
 #define GS_OPT_UNFUSED 5         /* 1 (default): projection, scan and emission are three launches; 0: experimental single fused launch
                                     (identical results; measured slower in round 1)                                              */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);

@@ -82,7 +82,7 @@ def test_frame_exact_mode(oracle, n, W, H, ts):
     r.wait()
     _check_stages(r, ref, exact_image=True, debug=False)
     r.set_option(_abi.GS_OPT_UNFUSED, 1)
-    r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)  # experimental: depth-ordered emission, tile-only instance sort
+    r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)  # depth-ordered emission, tile-only instance sort (auto-selected for big frames)
     r.render_uniforms(u)
     r.wait()
     _check_stages(r, ref, exact_image=True, debug=False)
