@@ -327,7 +327,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         uint32_t *gk = nullptr, *gperm = nullptr;
         gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
-                       c->n, 2, 5, 0, c->gsort_status, c->grid_persist, st, &gk, &gperm);
+                       c->n, 2, 5, 0, c->gsort_status, c->grid_persist, /*have_hist=*/true, st, &gk, &gperm);
         gs_launch_scan(c->counts, gperm, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table, (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks,
                        &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
@@ -344,10 +344,10 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     mark(c, 3);
     if (by_index)
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
+                       (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, st, &c->keysS, &c->valsS);
     else
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, st, &c->keysS, &c->valsS);
+                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, false, st, &c->keysS, &c->valsS);
     c->last_passes = by_index ? c->passes : c->tile_passes;
     c->last_by_index = by_index;
     mark(c, 4);
@@ -714,7 +714,7 @@ GS_EXPORT int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* va
     TRY2(hipMemcpy(&ctl->num_intersections, &n32, 4, hipMemcpyHostToDevice));
     uint32_t *ok = nullptr, *ov = nullptr;
     gs_launch_sort(kA, vA, kB, vB, ctl, ctl->sort_ticket, &ctl->hist[0][0], &ctl->num_intersections, n32, passes, 8, 0,
-                   (uint32_t*)((char*)ctl_mem + ctl_sz), (uint32_t)prop.multiProcessorCount * 4, nullptr, &ok, &ov);
+                   (uint32_t*)((char*)ctl_mem + ctl_sz), (uint32_t)prop.multiProcessorCount * 4, false, nullptr, &ok, &ov);
     TRY2(hipGetLastError());
     TRY2(hipDeviceSynchronize());
     uint32_t fault = 0;

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_wnz[4];
     __shared__ uint32_t s_prefix[2];
+    __shared__ uint32_t s_gh[64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = n_dev ? *n_dev : n_static;
     const uint32_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -129,14 +130,23 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
     run += s_prefix[0];
     run_nz += s_prefix[1];
     if (vkey) { // ordered compaction of the elements with a non-zero tile count
+        // ... and the digit histograms of the gaussian-level sort that follows (two 5-bit digits of the bucket):
+        // per-workgroup LDS counters, one global atomic per non-empty bin
+        for (uint32_t k = tid; k < 64u; k += 256u) s_gh[k] = 0u;
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) {
             if ((v[j] & GS_COUNT_MASK) != 0u) {
-                vkey[run_nz] = v[j] >> GS_COUNT_BITS;
+                const uint32_t bucket = v[j] >> GS_COUNT_BITS;
+                vkey[run_nz] = bucket;
                 vval[run_nz] = base + j;
                 ++run_nz;
+                atomicAdd(&s_gh[bucket & 31u], 1u);
+                atomicAdd(&s_gh[32u + ((bucket >> 5) & 31u)], 1u);
             }
         }
+        __syncthreads();
+        if (tid < 64u && s_gh[tid]) atomicAdd(&ctl->ghist[tid >> 5][tid & 31u], s_gh[tid]);
     }
     if (chunk_table) {
         uint32_t r2 = run;

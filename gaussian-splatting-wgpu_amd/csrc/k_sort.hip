@@ -69,22 +69,6 @@ __global__ __launch_bounds__(256) void gs_sort_hist_kernel(const uint32_t* __res
     }
 }
 
-// ---- exclusive scan of each 256-bin histogram (one workgroup; thread d owns bin d) ----------------
-__global__ __launch_bounds__(256) void gs_sort_hist_scan_kernel(uint32_t* __restrict__ hist, uint32_t passes) {
-    __shared__ uint32_t s_w[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (uint32_t p = 0; p < passes; ++p) {
-        const uint32_t c = hist[p * 256 + tid];
-        const uint32_t incl = wave_incl_scan(c, lane);
-        if (lane == 63) s_w[w] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t k = 0; k < w; ++k) base += s_w[k];
-        hist[p * 256 + tid] = base + incl - c;
-        __syncthreads();
-    }
-}
-
 // ---- one digit sweep ----------------------------------------------------------------------------------
 struct SweepShared {
     uint32_t hist[RS_WAVES][256];  // per-wave digit counts -> exclusive offsets across waves -> + digit start
@@ -226,17 +210,34 @@ __global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const uint
                                                              const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t pass,
                                                              SortDigits sd, uint32_t* status) {
     __shared__ SweepShared sh;
+    __shared__ uint32_t s_dbase[256]; // exclusive scan of this pass's digit histogram (first slot of every digit's run)
     uint32_t n = *n_ptr;
     if (n > capacity) n = capacity;
     const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+    {   // every workgroup scans the 256 raw counts itself: cheaper than a one-workgroup kernel between launches
+        const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+        uint32_t c = 0, incl = 0;
+        if (tid < 256u) {
+            c = hist[tid];
+            incl = wave_incl_scan(c, lane);
+            if (lane == 63) sh.wsum[w] = incl;
+        }
+        __syncthreads();
+        if (tid < 256u) {
+            uint32_t b = 0;
+            for (uint32_t k = 0; k < w; ++k) b += sh.wsum[k];
+            s_dbase[tid] = b + incl - c;
+        }
+        __syncthreads();
+    }
     for (;;) {
         if (threadIdx.x == 0) sh.tile = atomicAdd(ticket, 1u);
         __syncthreads();
         const uint32_t tile = sh.tile;
         if (tile >= ntiles) break; // uniform: every thread read the same ticket
         const uint32_t valid = (n - tile * RS_TILE < RS_TILE) ? n - tile * RS_TILE : RS_TILE;
-        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, hist, pass, sd, status, tile, valid);
-        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, hist, pass, sd, status, tile, valid);
+        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid);
+        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid);
         __syncthreads(); // LDS is reused by the next tile
     }
 }
@@ -246,14 +247,14 @@ uint32_t gs_sort_tiles(uint64_t capacity) { return (uint32_t)((capacity + RS_TIL
 // Sorts `n` (device word *n_ptr) pairs by `passes` digits of `bits` bits of the sort word (the key, or key/1000 when
 // by_tile).  Returns in *out_keys/*out_vals which of the two buffer pairs holds the result.  tickets[passes], hist[passes*256]
 // and status (passes * gs_sort_tiles(capacity) * 256 words) must have been zeroed by the caller.
+// have_hist: the caller already accumulated the digit counts into hist (the scan does it for the gaussian-level sort).
 void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
                     const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
-                    uint32_t grid, hipStream_t st, uint32_t** out_keys, uint32_t** out_vals) {
+                    uint32_t grid, bool have_hist, hipStream_t st, uint32_t** out_keys, uint32_t** out_vals) {
     SortDigits sd;
     sd.bits = bits;
     sd.by_tile = by_tile;
-    hipLaunchKernelGGL(gs_sort_hist_kernel, dim3(grid), dim3(256), 0, st, keysA, hist, n_ptr, capacity, passes, sd);
-    hipLaunchKernelGGL(gs_sort_hist_scan_kernel, dim3(1), dim3(256), 0, st, hist, passes);
+    if (!have_hist) hipLaunchKernelGGL(gs_sort_hist_kernel, dim3(grid), dim3(256), 0, st, keysA, hist, n_ptr, capacity, passes, sd);
     const uint64_t per_pass = (uint64_t)gs_sort_tiles(capacity) * 256;
     uint32_t *ki = keysA, *vi = valsA, *ko = keysB, *vo = valsB;
     for (uint32_t p = 0; p < passes; ++p) {
