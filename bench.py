@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--blend-ablation", type=int, default=0, help="profiling only: see GS_OPT_BLEND_ABLATION")
     ap.add_argument("--emit-order", type=int, default=-1, help="GS_OPT_EMIT_ORDER override (0 depth-ordered, 1 index order, 2 auto = default)")
+    ap.add_argument("--grid", type=int, default=0, help="GS_OPT_PERSISTENT_GRID override (workgroups of the ticket-loop kernels)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
@@ -157,6 +158,8 @@ def main():
                         stream=stream)
     del splats, pg
     torch.cuda.empty_cache()
+    if args.grid:
+        r.set_option(_abi.GS_OPT_PERSISTENT_GRID, args.grid)
     if args.emit_order >= 0:
         r.set_option(_abi.GS_OPT_EMIT_ORDER, args.emit_order)
     if args.blend_ablation:

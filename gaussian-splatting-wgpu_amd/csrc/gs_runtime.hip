@@ -331,7 +331,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         gs_launch_scan(c->counts, gperm, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table, (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks,
                        &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
-        gs_launch_emit_balanced(c->gdata, c->counts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist, st);
+        gs_launch_emit_balanced(c->gdata, c->counts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, st);
     }
     if (debug) {
         if (!c->keysU) {
@@ -351,7 +351,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     c->last_passes = by_index ? c->passes : c->tile_passes;
     c->last_by_index = by_index;
     mark(c, 4);
-    gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist, st);
+    gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, st); // streaming: 8 workgroups/CU
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
     const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, c->tile_depth, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
