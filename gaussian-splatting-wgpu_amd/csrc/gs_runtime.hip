@@ -569,6 +569,7 @@ GS_EXPORT int32_t gs_assemble_slabs(gs_ctx* c, const void* d_slabs, const uint32
 // zero-padded to 16 coefficients (the shader hard-codes 16: process_gaussians.wgsl:6).  The reference spends
 // "seconds to a couple of minutes" here in JS (index.html:16); this is a single pass over a read() of the file.
 #include <string>
+#include <thread>
 #include <vector>
 
 struct PlyProp { std::string name; int type; /* 0 other (0 bytes), 1 float, 2 uchar */ uint32_t offset; };
@@ -582,8 +583,16 @@ GS_EXPORT int32_t gs_ply_load(const char* path, void** records, uint64_t* n_out,
     fseek(fp, 0, SEEK_END);
     const long fsize = ftell(fp);
     fseek(fp, 0, SEEK_SET);
-    std::vector<unsigned char> buf((size_t)std::max<long>(fsize, 0));
-    if (fsize > 0 && fread(buf.data(), 1, (size_t)fsize, fp) != (size_t)fsize) { fclose(fp); return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: short read"); }
+    struct FileBuf { // uninitialised storage: a std::vector would spend a pass zero-filling it
+        unsigned char* p = nullptr; size_t n = 0;
+        ~FileBuf() { free(p); }
+        unsigned char* data() const { return p; }
+        size_t size() const { return n; }
+    } buf;
+    buf.n = (size_t)std::max<long>(fsize, 0);
+    buf.p = (unsigned char*)malloc(std::max<size_t>(buf.n, 1));
+    if (!buf.p) { fclose(fp); return fail(GS_ERR_OUT_OF_MEMORY, "gs_ply_load: out of host memory"); }
+    if (fsize > 0 && fread(buf.p, 1, (size_t)fsize, fp) != (size_t)fsize) { fclose(fp); return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: short read"); }
     fclose(fp);
     static const char kEnd[] = "end_header";
     size_t hdr_end = std::string::npos;
@@ -655,17 +664,34 @@ GS_EXPORT int32_t gs_ply_load(const char* path, void** records, uint64_t* n_out,
     if (buf.size() < data_off + vertex_count * (uint64_t)stride) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: vertex data truncated");
     float* out = (float*)calloc((size_t)std::max<uint64_t>(vertex_count, 1) * 80, sizeof(float));
     if (!out) return fail(GS_ERR_OUT_OF_MEMORY, "gs_ply_load: out of host memory");
-    const unsigned char* v = buf.data() + data_off;
-    for (uint64_t i = 0; i < vertex_count; ++i, v += stride) {
-        float* rec = out + i * 80;
-        for (int s = 0; s < nsrc; ++s) {
-            const PlyProp* p = src[s];
-            float f = 0.0f; // a property of another type reads as `undefined` in the reference; 0 here
-            if (p->type == 1) memcpy(&f, v + p->offset, 4);
-            else if (p->type == 2) f = (float)((double)v[p->offset] / 255.0);
-            rec[slot[s]] = f;
+    // flat (source offset, type, destination slot) table; vertices are independent, so the pass is split over threads
+    uint32_t soff[11 + 48], stype[11 + 48];
+    bool all_float = true;
+    for (int s2 = 0; s2 < nsrc; ++s2) { soff[s2] = src[s2]->offset; stype[s2] = (uint32_t)src[s2]->type; all_float = all_float && src[s2]->type == 1; }
+    const unsigned char* vbase = buf.data() + data_off;
+    auto work = [&](uint64_t i0, uint64_t i1) {
+        for (uint64_t i = i0; i < i1; ++i) {
+            const unsigned char* v = vbase + i * stride;
+            float* rec = out + i * 80;
+            if (all_float) {
+                for (int s2 = 0; s2 < nsrc; ++s2) memcpy(&rec[slot[s2]], v + soff[s2], 4);
+            } else {
+                for (int s2 = 0; s2 < nsrc; ++s2) {
+                    float f = 0.0f; // a property of another type reads as `undefined` in the reference; 0 here
+                    if (stype[s2] == 1) memcpy(&f, v + soff[s2], 4);
+                    else if (stype[s2] == 2) f = (float)((double)v[soff[s2]] / 255.0);
+                    rec[slot[s2]] = f;
+                }
+            }
         }
-    }
+    };
+    unsigned nthreads = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (vertex_count < 65536) nthreads = 1;
+    std::vector<std::thread> pool;
+    for (unsigned th = 1; th < nthreads; ++th)
+        pool.emplace_back(work, vertex_count * th / nthreads, vertex_count * (th + 1) / nthreads);
+    work(0, vertex_count / nthreads);
+    for (auto& th : pool) th.join();
     *records = out;
     *n_out = vertex_count;
     if (sh_degree) *sh_degree = degree;
