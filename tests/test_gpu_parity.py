@@ -266,3 +266,31 @@ def test_gpu_matches_committed_golden_vectors(path):
     f32 = r.read_buffer(_abi.GS_BUF_RGB_F32, np.float32)
     assert hashlib.sha256(f32.tobytes()).hexdigest() == str(g["rgbf_sha256"])
     r.destroy()
+
+
+def test_ply_file_to_frame(tmp_path, oracle):
+    """.ply on disk -> native loader (gs_ply_load / gs_upload_ply) -> frame, against the oracle
+    on the records the file was written from."""
+    import ctypes
+    import sys
+    sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
+    from ply_bench import write_ply
+    import gsplat
+    from gsplat import _abi
+    n, W, H = 12000, 320, 192
+    s, u = scene(n), _uniforms(W, H, step=14)
+    path = str(tmp_path / "scene.ply")
+    write_ply(path, s)
+    ref = oracle.render(s, u, W, H, 16)
+    pg = gsplat.PackedGaussians.from_ply(path)
+    assert pg.numGaussians == n and pg.sphericalHarmonicsDegree == 3
+    np.testing.assert_array_equal(np.asarray(pg.gaussiansBuffer).view(np.uint32), s.view(np.uint32))
+    r = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, 16, flags=_abi.GS_FLAG_EXACT_BLEND | _abi.GS_FLAG_F32_TAP)
+    # replace the scene through the one-call path as well
+    cnt = ctypes.c_uint64()
+    _abi.check(_abi.load().gs_upload_ply(r._ctx, path.encode(), ctypes.byref(cnt)))
+    assert cnt.value == n
+    r.render_uniforms(u, debug=True)
+    r.wait()
+    _check_stages(r, ref, exact_image=True)
+    r.destroy()
