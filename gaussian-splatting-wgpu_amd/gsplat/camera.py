@@ -55,20 +55,17 @@ def focal2fov(focal, pixels):
 
 
 def get_projection_matrix(znear, zfar, fov_x, fov_y):
-    """camera.ts:16-39 (fills a row-major P, returns its transpose => column-major)."""
-    tan_y, tan_x = math.tan(fov_y / 2), math.tan(fov_x / 2)
-    top, right = tan_y * znear, tan_x * znear
-    bottom, left = -top, -right
-    P = np.zeros(16, dtype=np.float32)
-    P[0] = (2.0 * znear) / (right - left)
-    P[5] = (2.0 * znear) / (top - bottom)
-    P[8] = (right + left) / (right - left)
-    P[9] = (top + bottom) / (top - bottom)
-    P[10] = zfar / (zfar - znear)
-    P[11] = -(zfar * znear) / (zfar - znear)
-    P[14] = 1.0
-    P[15] = 0.0
-    return mat4_transpose(P)
+    """camera.ts:16-39, written directly in column-major form (the reference fills a row-major matrix and
+    transposes it): x' = 2n/(r-l) x, y' = 2n/(t-b) y, z' = f/(f-n) z - fn/(f-n), w' = z; symmetric frustum."""
+    half_w, half_h = math.tan(0.5 * fov_x) * znear, math.tan(0.5 * fov_y) * znear
+    depth = zfar - znear
+    m = np.zeros(16, dtype=np.float32)
+    m[0] = (2.0 * znear) / (half_w + half_w)
+    m[5] = (2.0 * znear) / (half_h + half_h)
+    m[10] = zfar / depth
+    m[14] = -(zfar * znear) / depth
+    m[11] = 1.0
+    return m
 
 
 class Camera:

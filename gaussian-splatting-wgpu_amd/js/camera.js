@@ -5,66 +5,72 @@
 const fs = require('fs');
 const { mat4, mat3, vec3 } = require('./mat4');
 
+// Perspective matrix of camera.ts:16-39, written directly in the column-major form the reference obtains by
+// filling a row-major matrix and transposing it: x' = 2n/(r-l) x, y' = 2n/(t-b) y, z' = f/(f-n) z - fn/(f-n), w' = z
+// (symmetric frustum, so the (r+l) and (t+b) terms vanish).
 function getProjectionMatrix(znear, zfar, fovX, fovY) {
-  const tanHalfFovY = Math.tan(fovY / 2), tanHalfFovX = Math.tan(fovX / 2);
-  const top = tanHalfFovY * znear, bottom = -top, right = tanHalfFovX * znear, left = -right;
-  const P = mat4.create();
-  const zSign = 1.0;
-  P[0] = (2.0 * znear) / (right - left);
-  P[5] = (2.0 * znear) / (top - bottom);
-  P[8] = (right + left) / (right - left);
-  P[9] = (top + bottom) / (top - bottom);
-  P[10] = zSign * zfar / (zfar - znear);
-  P[11] = -(zfar * znear) / (zfar - znear);
-  P[14] = zSign;
-  P[15] = 0.0;
-  return mat4.transpose(P);
+  const halfW = Math.tan(0.5 * fovX) * znear;
+  const halfH = Math.tan(0.5 * fovY) * znear;
+  const depth = zfar - znear;
+  const m = new Float32Array(16);
+  m[0] = (2.0 * znear) / (halfW + halfW);
+  m[5] = (2.0 * znear) / (halfH + halfH);
+  m[10] = zfar / depth;
+  m[14] = -(zfar * znear) / depth;
+  m[11] = 1.0;
+  m[15] = 0.0;
+  return m;
 }
 
 function focal2fov(focal, pixels) { return 2 * Math.atan(pixels / (2 * focal)); }
 
+// world -> camera matrix of the reference's start-up view (the literal at camera.ts:90-107), column-major
+const DEFAULT_VIEW = [
+  0.582345724105835, -0.3235852122306824, 0.7372694611549377, 0,
+  0.23868794739246368, 0.9381394982337952, 0.22253619134426117, 0,
+  -0.7680802941322327, 0.04477229341864586, 0.6242981553077698, 0,
+  0.13517332077026367, -1.1848870515823364, 3.3873789310455322, 1,
+];
+
+// Same fields and methods as the reference's Camera (camera.ts:52-190); the pose edits go through the
+// inverse view matrix (camera-to-world) exactly as there.
 class Camera {
   constructor(height, width, viewMatrix, perspective, focalX, focalY, scaleModifier) {
-    this.height = height;
-    this.width = width;
-    this.viewMatrix = viewMatrix;
-    this.perspective = perspective;
-    this.focalX = focalX;
-    this.focalY = focalY;
-    this.scaleModifier = scaleModifier;
+    Object.assign(this, { height, width, viewMatrix, perspective, focalX, focalY, scaleModifier });
   }
 
+  // 800x800 canvas, focal 800, near 0.2, far 10 (camera.ts:79-122)
   static default(_canvas) {
-    const canvasW = 800, canvasH = 800, fovFactor = 1;
-    const fovX = focal2fov(canvasW, canvasW) / fovFactor, fovY = focal2fov(canvasH, canvasH) / fovFactor;
-    const projectionMatrix = getProjectionMatrix(0.2, 10, fovX, fovY);
-    const viewMatrix = mat4.create(
-      0.582345724105835, -0.3235852122306824, 0.7372694611549377, 0,
-      0.23868794739246368, 0.9381394982337952, 0.22253619134426117, 0,
-      -0.7680802941322327, 0.04477229341864586, 0.6242981553077698, 0,
-      0.13517332077026367, -1.1848870515823364, 3.3873789310455322, 1);
-    return new Camera(canvasW, canvasH, viewMatrix, projectionMatrix, canvasW, canvasH, 1 * fovFactor);
+    const size = 800;
+    const fov = focal2fov(size, size);
+    return new Camera(size, size, mat4.create(...DEFAULT_VIEW), getProjectionMatrix(0.2, 10, fov, fov), size, size, 1);
   }
 
   setScale(scale) { this.scaleModifier = scale; }
   setFocalX(focalX) { this.focalX = focalX; }
   setFocalY(focalY) { this.focalY = focalY; }
 
+  // camera position in world space = translation of the inverse view matrix (camera.ts:145-148)
   getPosition() { return mat4.getTranslation(mat4.inverse(this.viewMatrix)); }
+  // perspective * view (camera.ts:150-155)
   getProjMatrix() { return mat4.multiply(this.perspective, this.viewMatrix); }
 
-  translate(x, y, z) {
-    const viewInv = mat4.inverse(this.viewMatrix);
-    mat4.translate(viewInv, [x, y, z], viewInv);
-    mat4.inverse(viewInv, this.viewMatrix);
+  // post-multiplies the camera-to-world matrix by `edit` and inverts back (camera.ts:158-171)
+  _editPose(edit) {
+    const camToWorld = mat4.inverse(this.viewMatrix);
+    edit(camToWorld);
+    mat4.inverse(camToWorld, this.viewMatrix);
   }
 
+  translate(x, y, z) { this._editPose((m) => mat4.translate(m, [x, y, z], m)); }
+
+  // note the reference's argument order: `y` turns about X, `x` about Y (camera.ts:167-168)
   rotate(x, y, z) {
-    const viewInv = mat4.inverse(this.viewMatrix);
-    mat4.rotateX(viewInv, y, viewInv);
-    mat4.rotateY(viewInv, x, viewInv);
-    mat4.rotateZ(viewInv, z, viewInv);
-    mat4.inverse(viewInv, this.viewMatrix);
+    this._editPose((m) => {
+      mat4.rotateX(m, y, m);
+      mat4.rotateY(m, x, m);
+      mat4.rotateZ(m, z, m);
+    });
   }
 
   // The 160-byte uniform block Renderer.animate packs (renderer.ts:15-24,362-392).
@@ -94,14 +100,11 @@ class InteractiveCamera {
 
   static default(canvas) { return new InteractiveCamera(Camera.default(canvas), canvas); }
 
+  // keyboard deltas of camera.ts:251-278 as a table: key -> [field, step]
   key(k) {
-    const keyMap = {
-      w: () => { this.dTY -= 0.1; }, s: () => { this.dTY += 0.1; }, a: () => { this.dTX -= 0.1; }, d: () => { this.dTX += 0.1; },
-      q: () => { this.dTZ += 0.1; }, e: () => { this.dTZ -= 0.1; }, j: () => { this.dRX += 0.1; }, l: () => { this.dRX -= 0.1; },
-      i: () => { this.dRY += 0.1; }, k: () => { this.dRY -= 0.1; }, u: () => { this.dRZ += 0.1; }, o: () => { this.dRZ -= 0.1; },
-    };
-    if (!keyMap[k]) return false;
-    keyMap[k]();
+    const step = InteractiveCamera.KEY_STEPS[k];
+    if (!step) return false;
+    this[step[0]] += step[1];
     this.dirty = true;
     return true;
   }
@@ -128,21 +131,20 @@ class InteractiveCamera {
   }
 }
 
-function worldToCamFromRT(R, t) {
-  const camToWorld = mat4.fromMat3(R);
-  const minusT = vec3.mulScalar(t, -1);
-  mat4.translate(camToWorld, minusT, camToWorld);
-  return camToWorld;
-}
+InteractiveCamera.KEY_STEPS = {
+  w: ['dTY', -0.1], s: ['dTY', 0.1], a: ['dTX', -0.1], d: ['dTX', 0.1], q: ['dTZ', 0.1], e: ['dTZ', -0.1],
+  j: ['dRX', 0.1], l: ['dRX', -0.1], i: ['dRY', 0.1], k: ['dRY', -0.1], u: ['dRZ', 0.1], o: ['dRZ', -0.1],
+};
 
+// 3DGS cameras.json entry -> Camera (camera.ts:314-340): the rows of `rotation` become the columns of the 3x3 block
+// (mat3.create(...rotation.flat())), followed by a translation by -position: view = [R^T | 0] * T(-position).
 function cameraFromJSON(rawCamera, _canvasW, _canvasH) {
-  const canvW = 800, canvH = 800;
-  const fovX = focal2fov(canvW, canvW), fovY = focal2fov(canvH, canvH);
-  const projectionMatrix = getProjectionMatrix(0.2, 100, fovX, fovY);
+  const size = 800;
+  const fov = focal2fov(size, size);
   const flat = [].concat(...rawCamera.rotation);
-  const R = mat3.create(...flat);
-  const viewMatrix = worldToCamFromRT(R, rawCamera.position);
-  return new Camera(canvH, canvW, viewMatrix, projectionMatrix, canvW, canvH, 1);
+  const view = mat4.fromMat3(mat3.create(...flat));
+  mat4.translate(view, vec3.mulScalar(rawCamera.position, -1), view);
+  return new Camera(size, size, view, getProjectionMatrix(0.2, 100, fov, fov), size, size, 1);
 }
 
 // CameraFileParser (camera.ts:344-400) without the <ul> UI: returns [{name, camera}].
