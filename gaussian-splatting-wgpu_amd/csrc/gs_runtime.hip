@@ -75,6 +75,7 @@ struct gs_ctx {
     uint32_t* gsort_status = nullptr;           // gaussian-level sort by depth bucket
     uint32_t* sort_status = nullptr;            // instance sort
     uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
+    uint32_t* scounts = nullptr;                // tile-count words of the visible gaussians in depth-sorted order
     uint32_t last_passes = 0;
     bool last_by_index = true;
     uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
@@ -213,7 +214,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_kv(c);
     hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB);
+    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->have_events)
@@ -226,7 +227,8 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
 
 static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB);
+    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
+    c->scounts = nullptr;
     c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
     c->vkeyA = c->vvalA = c->vkeyB = c->vvalB = nullptr;
     c->n = (uint32_t)n;
@@ -246,6 +248,7 @@ static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     HIP_TRY(hipMalloc((void**)&c->vvalA, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->vkeyB, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->vvalB, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->scounts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
     if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
@@ -326,12 +329,14 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         // sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
         gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         uint32_t *gk = nullptr, *gperm = nullptr;
+        // the last gaussian-level sweep also gathers the tile-count words into sorted order (c->scounts), so the second
+        // scan and the emission read them coalesced
         gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
-                       c->n, 2, 5, 0, c->gsort_status, c->grid_persist, /*have_hist=*/true, st, &gk, &gperm);
-        gs_launch_scan(c->counts, gperm, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table, (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks,
-                       &c->ctl->scan_ticket[1], c->ctl, 0u, st);
+                       c->n, 2, 5, 0, c->gsort_status, c->grid_persist, /*have_hist=*/true, c->counts, c->scounts, st, &gk, &gperm);
+        gs_launch_scan(c->scounts, nullptr, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table,
+                       (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
-        gs_launch_emit_balanced(c->gdata, c->counts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, st);
+        gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, st);
     }
     if (debug) {
         if (!c->keysU) {
@@ -344,10 +349,10 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     mark(c, 3);
     if (by_index)
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, st, &c->keysS, &c->valsS);
+                       (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
     else
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, false, st, &c->keysS, &c->valsS);
+                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
     c->last_passes = by_index ? c->passes : c->tile_passes;
     c->last_by_index = by_index;
     mark(c, 4);
@@ -740,7 +745,7 @@ GS_EXPORT int32_t gs_sort_pairs_u32(int32_t device, uint32_t* keys, uint32_t* va
     TRY2(hipMemcpy(&ctl->num_intersections, &n32, 4, hipMemcpyHostToDevice));
     uint32_t *ok = nullptr, *ov = nullptr;
     gs_launch_sort(kA, vA, kB, vB, ctl, ctl->sort_ticket, &ctl->hist[0][0], &ctl->num_intersections, n32, passes, 8, 0,
-                   (uint32_t*)((char*)ctl_mem + ctl_sz), (uint32_t)prop.multiProcessorCount * 4, false, nullptr, &ok, &ov);
+                   (uint32_t*)((char*)ctl_mem + ctl_sz), (uint32_t)prop.multiProcessorCount * 4, false, nullptr, nullptr, nullptr, &ok, &ov);
     TRY2(hipGetLastError());
     TRY2(hipDeviceSynchronize());
     uint32_t fault = 0;

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
             uint32_t off = 0xFFFFFFFFu, row = 0, yb = 0, gid = 0, cnt = 0;
             if (k < nvis) {
                 gid = perm[k];
-                const uint32_t packed = counts[gid];
+                const uint32_t packed = counts[k]; // sorted order, like offsets and perm
                 cnt = packed & GS_COUNT_MASK;
                 off = offsets[k];
                 const uint4 rect = gdata[(uint64_t)gid * 4 + 3];

@@ -83,7 +83,8 @@ template <bool FULL>
 __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, GsControl* ctl,
                                            const uint32_t* __restrict__ hist, uint32_t pass, SortDigits sd, uint32_t* status,
-                                           uint32_t tile, uint32_t valid) {
+                                           uint32_t tile, uint32_t valid, const uint32_t* __restrict__ aux_table,
+                                           uint32_t* __restrict__ aux_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wbase = w * (64 * RS_ITEMS) + lane; // this lane's first slot in the tile
@@ -198,8 +199,10 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
         if (FULL || pos < valid) {
             const uint32_t k = sh.keys[pos];
             const uint32_t g = sh.gbase[sort_digit(k, pass, sd)] + pos;
+            const uint32_t pv = sh.vals[pos];
             keys_out[g] = k;
-            vals_out[g] = sh.vals[pos];
+            vals_out[g] = pv;
+            if (aux_out) aux_out[g] = aux_table[pv]; // last sweep of the gaussian-level sort: tile counts in sorted order
         }
     }
 }
@@ -208,7 +211,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const uint
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              GsControl* ctl, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t pass,
-                                                             SortDigits sd, uint32_t* status) {
+                                                             SortDigits sd, uint32_t* status, const uint32_t* __restrict__ aux_table,
+                                                             uint32_t* __restrict__ aux_out) {
     __shared__ SweepShared sh;
     __shared__ uint32_t s_dbase[256]; // exclusive scan of this pass's digit histogram (first slot of every digit's run)
     uint32_t n = *n_ptr;
@@ -236,8 +240,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const uint
         const uint32_t tile = sh.tile;
         if (tile >= ntiles) break; // uniform: every thread read the same ticket
         const uint32_t valid = (n - tile * RS_TILE < RS_TILE) ? n - tile * RS_TILE : RS_TILE;
-        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid);
-        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid);
+        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid, aux_table, aux_out);
+        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid, aux_table, aux_out);
         __syncthreads(); // LDS is reused by the next tile
     }
 }
@@ -248,9 +252,11 @@ uint32_t gs_sort_tiles(uint64_t capacity) { return (uint32_t)((capacity + RS_TIL
 // by_tile).  Returns in *out_keys/*out_vals which of the two buffer pairs holds the result.  tickets[passes], hist[passes*256]
 // and status (passes * gs_sort_tiles(capacity) * 256 words) must have been zeroed by the caller.
 // have_hist: the caller already accumulated the digit counts into hist (the scan does it for the gaussian-level sort).
+// aux_table/aux_out (optional): the last sweep also writes aux_out[i] = aux_table[value_i] in sorted order.
 void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
                     const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
-                    uint32_t grid, bool have_hist, hipStream_t st, uint32_t** out_keys, uint32_t** out_vals) {
+                    uint32_t grid, bool have_hist, const uint32_t* aux_table, uint32_t* aux_out, hipStream_t st, uint32_t** out_keys,
+                    uint32_t** out_vals) {
     SortDigits sd;
     sd.bits = bits;
     sd.by_tile = by_tile;
@@ -258,8 +264,10 @@ void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t*
     const uint64_t per_pass = (uint64_t)gs_sort_tiles(capacity) * 256;
     uint32_t *ki = keysA, *vi = valsA, *ko = keysB, *vo = valsB;
     for (uint32_t p = 0; p < passes; ++p) {
+        const bool last = (p + 1 == passes);
         hipLaunchKernelGGL(gs_sort_sweep_kernel, dim3(grid), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, ctl, tickets + p, hist + p * 256, n_ptr,
-                           capacity, p, sd, status + p * per_pass);
+                           capacity, p, sd, status + p * per_pass, last ? aux_table : (const uint32_t*)nullptr,
+                           last ? aux_out : (uint32_t*)nullptr);
         uint32_t* t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
     }
