@@ -16,7 +16,7 @@ uint64_t gs_emit_chunks(uint64_t capacity);
 // counts: tile-count words in the SAME order as offsets/perm (sorted order)
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                              const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
-                             hipStream_t st);
+                             uint32_t hist_bits, uint32_t hist_passes, hipStream_t st);
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,

@@ -336,7 +336,8 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         gs_launch_scan(c->scounts, nullptr, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table,
                        (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
-        gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, st);
+        gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
+                                c->tile_bits, c->tile_passes, st);
     }
     if (debug) {
         if (!c->keysU) {
@@ -352,7 +353,8 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
                        (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
     else
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
+                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, /*have_hist=*/true, nullptr, nullptr, st,
+                       &c->keysS, &c->valsS);
     c->last_passes = by_index ? c->passes : c->tile_passes;
     c->last_by_index = by_index;
     mark(c, 4);

@@ -278,8 +278,12 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
                                                                 const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
                                                                 const uint32_t* __restrict__ chunk_table, GsFrame f,
                                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ values,
-                                                                GsControl* ctl) {
+                                                                GsControl* ctl, uint32_t hist_bits, uint32_t hist_passes) {
     __shared__ uint32_t s_off[4][64];
+    __shared__ uint32_t s_hist[4][256]; // digit counts of the instance sort (digits of key/1000), flushed once per workgroup
+    for (uint32_t k = threadIdx.x; k < 4 * 256; k += 256) (&s_hist[0][0])[k] = 0u;
+    __syncthreads();
+    const uint32_t hmask = (1u << hist_bits) - 1u;
     __shared__ uint32_t s_row[4][64]; // xa | wmain<<16 | alias<<31
     __shared__ uint32_t s_yb[4][64];  // y0 | bucket<<16
     __shared__ uint32_t s_gid[4][64];
@@ -338,14 +342,26 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
                 const uint32_t yy = local / wtot, xx = local - yy * wtot;
                 const uint32_t px = (xx < wmain) ? xa + xx : f.ntx;
                 const uint32_t py = (y_b & 0xFFFFu) + yy;
-                keys[x] = (py * f.ntx + px) * 1000u + (y_b >> 16);
+                const uint32_t tile_id = py * f.ntx + px;
+                keys[x] = tile_id * 1000u + (y_b >> 16);
                 values[x] = s_gid[w][lo];
+                // the instance sort that follows orders by digits of the tile id: count them here, where the key is
+                // in a register, instead of re-reading all keys in a histogram kernel
+                atomicAdd(&s_hist[0][tile_id & hmask], 1u);
+                if (hist_passes > 1) atomicAdd(&s_hist[1][(tile_id >> hist_bits) & hmask], 1u);
+                if (hist_passes > 2) atomicAdd(&s_hist[2][(tile_id >> (2 * hist_bits)) & hmask], 1u);
+                if (hist_passes > 3) atomicAdd(&s_hist[3][(tile_id >> (3 * hist_bits)) & hmask], 1u);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             e = stop;
             kbase += 64;
         }
+    }
+    __syncthreads();
+    for (uint32_t p = 0; p < hist_passes; ++p) {
+        const uint32_t c = s_hist[p][threadIdx.x];
+        if (c) atomicAdd(&ctl->hist[p][threadIdx.x], c);
     }
 }
 
@@ -404,9 +420,9 @@ void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32
 uint64_t gs_emit_chunks(uint64_t capacity) { return (capacity >> EMIT_CHUNK_SHIFT) + 2; }
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                              const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
-                             hipStream_t st) {
+                             uint32_t hist_bits, uint32_t hist_passes, hipStream_t st) {
     hipLaunchKernelGGL(gs_emit_balanced_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, chunk_table, f, keys,
-                       values, ctl);
+                       values, ctl, hist_bits, hist_passes);
 }
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st) {
