@@ -23,6 +23,7 @@
 // Bound: f32 VALU + transcendental issue (about 22 VALU slots per pixel x entry), not HBM:
 // algorithmic bytes are 40 B per staged entry + 4 B per pixel.
 #include "gs_device.h"
+#include <type_traits>
 
 // Minimum over the pixel block [dxlo,dxhi] x [dylo,dyhi] (offsets g - p) of the quadratic
 // q(d) = 0.5*(cx*dx^2 + cz*dy^2) + cy*dx*dy (power = -q).  For a positive-definite conic whose centre
@@ -421,13 +422,24 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     __shared__ float4 sP1[64];
     __shared__ float4 sP2[64];
     const uint32_t lane = threadIdx.x;
-    const uint32_t slab_tx = f.col1 - f.col0, ntl = slab_tx * f.nty;
-    // workgroup b: group of 32 = 8 tiles x 4 quadrants; quadrant = (b / 8) % 4, tile = (b / 32) * 8 + b % 8
+    const uint32_t slab_tx = f.col1 - f.col0;
+    // Workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own L2.  XCD x owns the column strips
+    // x, x+8, ... (a strip = SW tile columns) and walks its tiles row-major, the 4 quadrants of a tile next to each
+    // other: the tiles one splat covers are then mostly blended on ONE XCD and close in time, so more of the gathers
+    // of its record hit in that L2 (a placement hint only - correctness does not depend on it).  SW = 3 measured best
+    // (config B: 1 -> 1002 us, 2 -> 993, 3 -> 932, 5 -> 945, 8 -> 970, 15 -> 983).
     const uint32_t b = blockIdx.x;
-    const uint32_t q = (b >> 3) & 3u;
-    const uint32_t lin = (b >> 5) * 8u + (b & 7u);
-    if (lin >= ntl) return;
-    const uint32_t tx = f.col0 + lin % slab_tx, ty = lin / slab_tx;
+    const uint32_t x = b & 7u, j = b >> 3, q = j & 3u, t = j >> 2;
+    const uint32_t SW = (dbg >> 8) & 0xffu;
+    const uint32_t ns = (slab_tx + SW - 1) / SW; // strips in this slab
+    if (x >= ns) return;
+    const uint32_t n_x = (ns - 1 - x) / 8 + 1;
+    const uint32_t lastw = slab_tx - (ns - 1) * SW;
+    const uint32_t Wx = n_x * SW - ((((ns - 1) & 7u) == x) ? SW - lastw : 0u); // tile columns owned by XCD x
+    if (t >= Wx * f.nty) return;
+    const uint32_t ty = t / Wx, cc = t % Wx;
+    const uint32_t tx = f.col0 + (x + 8u * (cc / SW)) * SW + cc % SW;
+    const uint32_t lin = ty * slab_tx + (tx - f.col0);
     const uint32_t tile = tx + ty * f.ntx;
     const uint32_t start = tile > 0 ? ranges[tile - 1] : 0u;
     uint32_t end = ranges[tile];
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     for (uint32_t bb = start; bb < end; bb += 64) {
         const uint32_t cnt = (end - bb < 64u) ? end - bb : 64u;
         staged += cnt;
-        bool rel = false;
+        bool rel = false, npd = false;
         if (lane < cnt) {
             const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
             const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
@@ -472,11 +484,21 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
             float mag;
             const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
             rel = (!pd || !(qm > lim + 1.0e-5f * mag)) && !(dbg & 1u);
+            npd = rel && !pd;
             if (rel) { // only surviving entries are parked for the broadcast
                 const float L = 1.44269502162933349609375f;
-                sP0[lane] = make_float4(gxp, gyp, 0.0f, 0.0f);
-                sP1[lane] = EXACT ? make_float4(cx, cy, cz, 0.0f) : make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, 0.0f);
-                sP2[lane] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
+                // LDS reads are priced by width (ds_read_b64 2 cycles, b128 4, b96 8 - the loop is LDS-array bound as much as
+                // VALU bound), so the fused layout is two full float4 and one float: (x, y, r, g) (conic', log2 op) (b).
+                // The opacity rides in the exponent: alpha = exp2(power*log2(e) + log2(op)).
+                if (EXACT) {
+                    sP0[lane] = make_float4(gxp, gyp, 0.0f, 0.0f);
+                    sP1[lane] = make_float4(cx, cy, cz, 0.0f);
+                    sP2[lane] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
+                } else {
+                    sP0[lane] = make_float4(gxp, gyp, __uint_as_float(r2.x), __uint_as_float(r2.y));
+                    sP1[lane] = make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, __builtin_amdgcn_logf(op));
+                    sP2[lane].x = __uint_as_float(r2.z); // 16-byte stride: one address register serves all three reads
+                }
             }
         }
         const uint32_t nb = bb + 64;
@@ -489,37 +511,48 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         unsigned long long m = __ballot(rel);
         evaluated += (uint32_t)__popcll(m);
-        while (m) {
-            const uint32_t e = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1ull;
-            const float4 p0 = sP0[e];
-            const float4 p1 = sP1[e];
-            const float4 p2v = sP2[e];
-            const float dx = p0.x - pxf, dy = p0.y - pyf;
-            if (EXACT) {
-                const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
-                const float power = -0.5f * (t1 + t2) - t3;
-                const float alpha = wg_min(0.99f, p2v.w * gs_exp(power));
-                const float test = T * (1.0f - alpha);
-                const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
-                cr += cond * p2v.x * alpha * T;
-                cg += cond * p2v.y * alpha * T;
-                cb += cond * p2v.z * alpha * T;
-                T = cond * test + (1.0f - cond) * T;
-            } else {
-                const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
-                const float v = (p1.z * dy) * dy;
-                const float pw = __builtin_fmaf(dx, u, v); // power * log2(e)
-                const float alpha = __builtin_fminf(0.99f, p2v.w * __builtin_amdgcn_exp2f(pw));
-                const float test = __builtin_fmaf(-T, alpha, T);
-                const bool keep = (pw <= 0.0f) && (alpha >= c255) && (test >= 0.0001f);
-                const float wgt = (keep ? alpha : 0.0f) * T;
-                cr = __builtin_fmaf(p2v.x, wgt, cr);
-                cg = __builtin_fmaf(p2v.y, wgt, cg);
-                cb = __builtin_fmaf(p2v.z, wgt, cb);
-                T = keep ? test : T;
+        // The reference skips an entry whose power is > 0; for a positive-definite conic the power cannot be (beyond
+        // rounding, which the oracle's ill-conditioning margin covers), so the fused loop only pays for that compare in
+        // a batch that holds a survivor with a non-positive-definite conic (never produced by the projection's +0.3
+        // low-pass; NaN records land here too).
+        auto walk = [&](auto checked_tag) {
+            constexpr bool CHECKED = decltype(checked_tag)::value;
+            while (m) {
+                const uint32_t e = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const float4 p0 = sP0[e];
+                const float4 p1 = sP1[e];
+                const float dx = p0.x - pxf, dy = p0.y - pyf;
+                if (EXACT) {
+                    const float4 p2v = sP2[e];
+                    const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
+                    const float power = -0.5f * (t1 + t2) - t3;
+                    const float alpha = wg_min(0.99f, p2v.w * gs_exp(power));
+                    const float test = T * (1.0f - alpha);
+                    const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
+                    cr += cond * p2v.x * alpha * T;
+                    cg += cond * p2v.y * alpha * T;
+                    cb += cond * p2v.z * alpha * T;
+                    T = cond * test + (1.0f - cond) * T;
+                } else {
+                    const float colb = sP2[e].x;
+                    const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
+                    const float v = __builtin_fmaf(p1.z * dy, dy, p1.w);
+                    const float pw = __builtin_fmaf(dx, u, v); // power * log2(e) + log2(op)
+                    const float alpha = __builtin_fminf(0.99f, __builtin_amdgcn_exp2f(pw));
+                    const float test = __builtin_fmaf(-T, alpha, T);
+                    bool keep = (alpha >= c255) && (test >= 0.0001f);
+                    if (CHECKED) keep = keep && (pw <= p1.w); // power <= 0
+                    const float wgt = (keep ? alpha : 0.0f) * T;
+                    cr = __builtin_fmaf(p0.z, wgt, cr);
+                    cg = __builtin_fmaf(p0.w, wgt, cg);
+                    cb = __builtin_fmaf(colb, wgt, cb);
+                    T = keep ? test : T;
+                }
             }
-        }
+        };
+        if (EXACT || __ballot(npd) != 0ull) walk(std::true_type{});
+        else walk(std::false_type{});
         if (EXACT) done = outside || (T * (1.0f - c255) < 0.0001f);
         else done = outside || (__builtin_fmaf(-T, c255, T) < 0.0001f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -577,7 +610,7 @@ static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* g
 // tile_depth[], the per-tile maximum over its four independent walkers), 1 otherwise (ctl->num_processed).
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
                     GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, hipStream_t st) {
-    const uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
+    uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
     const dim3 grid(f.col1 - f.col0, f.nty);
     if (grid.x == 0 || grid.y == 0) return 1;
     const uint4* g = (const uint4*)gdata;
@@ -590,10 +623,21 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
         // (8 = 4-wave workgroup per tile, 16 = one wave per whole tile)
         const bool wave = (dbg & 16u) != 0;
         if (!(dbg & (8u | 16u))) {
-            const uint32_t nt = grid.x * grid.y;
-            const uint32_t nblk = ((nt + 7) / 8) * 32;
-            if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
-            else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+            uint32_t SW = (dbg >> 8) & 0xffu; // strip width override (GS_OPT_BLEND_ABLATION bits 8..15), default 3
+            if (!SW) SW = 3;
+            dbg = (dbg & 0xffu) | (SW << 8);
+            const uint32_t slab_tx = grid.x, ns = (slab_tx + SW - 1) / SW, lastw = slab_tx - (ns - 1) * SW;
+            uint32_t wmax = 0;
+            for (uint32_t x = 0; x < 8 && x < ns; ++x) {
+                const uint32_t n_x = (ns - 1 - x) / 8 + 1, wx = n_x * SW - ((((ns - 1) & 7u) == x) ? SW - lastw : 0u);
+                wmax = wx > wmax ? wx : wmax;
+            }
+            const uint32_t nblk = 32u * wmax * grid.y;
+            // PROFILING ONLY: bits 6/7 reserve dynamic LDS so that only 2 / 4 waves fit a SIMD (occupancy sensitivity:
+            // config B 8 waves -> 982 us, 4 -> 1214, 2 -> 1890)
+            const uint32_t pad = (dbg & 64u) ? 20480u - 3072u : (dbg & 128u) ? 10240u - 3072u : 0u;
+            if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+            else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
             return 4;
         }
         if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; }

@@ -103,7 +103,7 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
-@pytest.mark.parametrize("variant", [0, 8, 16])  # GS_OPT_BLEND_ABLATION: 0 = default (quadrant waves), 8 = 4-wave workgroup per tile, 16 = whole-tile wave
+@pytest.mark.parametrize("variant", [0, 8, 16, 32, 5 * 256])  # GS_OPT_BLEND_ABLATION: 0 = default (quadrant waves), 8 = 4-wave workgroup per tile, 16 = whole-tile wave, 32 = the other gather of the quadrant kernel, 5<<8 = strip width 5
 @pytest.mark.parametrize("exact", [True, False])
 def test_blend_kernel_variants(oracle, variant, exact):
     from gsplat import _abi
