@@ -96,6 +96,28 @@ def cpu_baseline(n_full, W, H, seed, sample_n):
     }
 
 
+def copy_probe(dev, nbytes=512 << 20, iters=10):
+    """Device-to-device copy of `nbytes` (outside the timed region): the practical HBM ceiling of this box, reported
+    beside the 8 TB/s nominal peak the roofline fractions are quoted against."""
+    import torch
+    a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    b = torch.empty_like(a)
+    a.zero_()
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    del a, b
+    return {"bytes_copied": nbytes, "us": round(us, 1), "GBps_read_plus_write": round(2 * nbytes / (us * 1e-6) / 1e9, 1),
+            "nominal_peak_GBps": HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +270,9 @@ def main():
             line["frame_us_device"] = round(st["frame_us_mean"], 2)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(N, W, H, seed, args.cpu_sample)
+            line["copy_probe"] = copy_probe(dev)
+            # the reference itself (WGSL on a WebGPU runtime, TypeScript host) cannot run on this box
+            line["webgpu_baseline"] = "unavailable (no WebGPU runtime, no TypeScript toolchain, no network)"
         print(json.dumps(line), flush=True)
     r.destroy()
     if world > 1:

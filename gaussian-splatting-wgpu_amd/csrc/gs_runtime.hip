@@ -296,10 +296,12 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     mark(c, 0);
     if (c->emit_order == 2) {
         // auto: the depth-ordered pipeline saves (passes - tile_passes) full sweeps of the instance arrays (16 B per
-        // instance each, ~3 TB/s) and costs ~250 us of small gaussian-level kernels: worth it on a whole canvas once the
-        // previous frame's instance count times the sweeps saved exceeds ~37 M (1080p/42 M: break-even; 4K/134 M: +30 %)
+        // instance each, ~3 TB/s) and the histogram pass, and costs ~100 us of gaussian-level kernels whose time does not
+        // shrink with the slab (a scan over all N counts, two small sweeps, a second scan).  Measured break-even with one
+        // sweep saved: I ~ 13 M (1080p whole canvas, 42 M: -135 us; 2-GPU slab, 21 M: -45 us; 4-GPU slab, 11 M: +10 us;
+        // 8-GPU slab, 5 M: +15 us), so: depth order once (sweeps saved) x (previous frame's I) >= 15 M.
         const uint64_t saved = c->passes > c->tile_passes ? c->passes - c->tile_passes : 0;
-        c->index_order = !(f.full && c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 37000000ull);
+        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 15000000ull);
     } else {
         c->index_order = (c->emit_order == 1);
     }

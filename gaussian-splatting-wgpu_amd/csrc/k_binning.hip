@@ -21,7 +21,9 @@
 #define EMIT_CHUNK_SHIFT 10
 #define EMIT_CHUNK (1u << EMIT_CHUNK_SHIFT) // output slots one wave emits at a time in the balanced emission
 #define SCAN_ITEMS 16
-#define SCAN_TILE (256 * SCAN_ITEMS)
+#define SCAN_THREADS 1024 // 16 waves: the look-back chain advances 64 workgroups per step, so fewer, larger workgroups finish sooner
+#define SCAN_WAVES (SCAN_THREADS / 64)
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 #define ST_AGG (1ull << 62)
 #define ST_PREFIX (2ull << 62)
 #define ST_MASK (3ull << 62)
@@ -34,15 +36,15 @@
 //   vkey/vval: optional ordered compaction of the non-zero elements: (bucket, element index)
 //   chunk_table: optional; chunk_table[c] = the element whose instances contain output slot c*EMIT_CHUNK, which
 //              lets the balanced emission start every chunk without searching
-__global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ gather,
+__global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ gather,
                                                        const uint32_t* __restrict__ n_dev, uint32_t n_static,
                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ vkey,
                                                        uint32_t* __restrict__ vval, uint32_t* __restrict__ chunk_table,
                                                        uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
                                                        GsControl* ctl, uint32_t write_totals) {
     __shared__ uint32_t s_bid;
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_wnz[4];
+    __shared__ uint32_t s_wsum[SCAN_WAVES];
+    __shared__ uint32_t s_wnz[SCAN_WAVES];
     __shared__ uint32_t s_prefix[2];
     __shared__ uint32_t s_gh[64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
     __syncthreads();
     uint32_t wave_excl = 0, block_total = 0, wave_excl_nz = 0, block_nz = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SCAN_WAVES; ++k) {
         const uint32_t t = s_wsum[k], z = s_wnz[k];
         if (k < (int)w) { wave_excl += t; wave_excl_nz += z; }
         block_total += t;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void gs_scan_kernel(const uint32_t* __restrict
     if (vkey) { // ordered compaction of the elements with a non-zero tile count
         // ... and the digit histograms of the gaussian-level sort that follows (two 5-bit digits of the bucket):
         // per-workgroup LDS counters, one global atomic per non-empty bin
-        for (uint32_t k = tid; k < 64u; k += 256u) s_gh[k] = 0u;
+        if (tid < 64u) s_gh[tid] = 0u;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) {
@@ -414,7 +416,7 @@ void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32
                     GsControl* ctl, uint32_t write_totals, hipStream_t st) {
     const uint32_t blocks = gs_scan_blocks(n_static);
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(256), 0, st, counts, gather, n_dev, n_static, offsets, vkey, vval, chunk_table,
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(SCAN_THREADS), 0, st, counts, gather, n_dev, n_static, offsets, vkey, vval, chunk_table,
                        chunk_cap, status, ticket, ctl, write_totals);
 }
 uint64_t gs_emit_chunks(uint64_t capacity) { return (capacity >> EMIT_CHUNK_SHIFT) + 2; }

@@ -623,15 +623,27 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
         // (8 = 4-wave workgroup per tile, 16 = one wave per whole tile)
         const bool wave = (dbg & 16u) != 0;
         if (!(dbg & (8u | 16u))) {
-            uint32_t SW = (dbg >> 8) & 0xffu; // strip width override (GS_OPT_BLEND_ABLATION bits 8..15), default 3
-            if (!SW) SW = 3;
-            dbg = (dbg & 0xffu) | (SW << 8);
-            const uint32_t slab_tx = grid.x, ns = (slab_tx + SW - 1) / SW, lastw = slab_tx - (ns - 1) * SW;
-            uint32_t wmax = 0;
-            for (uint32_t x = 0; x < 8 && x < ns; ++x) {
-                const uint32_t n_x = (ns - 1 - x) / 8 + 1, wx = n_x * SW - ((((ns - 1) & 7u) == x) ? SW - lastw : 0u);
-                wmax = wx > wmax ? wx : wmax;
+            // strip width: the widest of 3, 2, 1 tile columns that still spreads the slab's columns evenly over the 8 XCDs
+            // (120 or 240 columns -> 3; a 60-column slab -> 2; 30- and 15-column slabs -> 1); GS_OPT_BLEND_ABLATION
+            // bits 8..15 override it
+            const uint32_t slab_tx = grid.x;
+            auto widest = [&](uint32_t sw) {
+                const uint32_t ns = (slab_tx + sw - 1) / sw, lastw = slab_tx - (ns - 1) * sw;
+                uint32_t wmax = 0;
+                for (uint32_t x = 0; x < 8 && x < ns; ++x) {
+                    const uint32_t n_x = (ns - 1 - x) / 8 + 1, wx = n_x * sw - ((((ns - 1) & 7u) == x) ? sw - lastw : 0u);
+                    wmax = wx > wmax ? wx : wmax;
+                }
+                return wmax;
+            };
+            uint32_t SW = (dbg >> 8) & 0xffu;
+            if (!SW) {
+                SW = 1;
+                for (uint32_t sw = 3; sw > 1; --sw)
+                    if (widest(sw) * 80u <= slab_tx * 11u) { SW = sw; break; } // within 10 % of slab_tx / 8
             }
+            dbg = (dbg & 0xffu) | (SW << 8);
+            const uint32_t wmax = widest(SW);
             const uint32_t nblk = 32u * wmax * grid.y;
             // PROFILING ONLY: bits 6/7 reserve dynamic LDS so that only 2 / 4 waves fit a SIMD (occupancy sensitivity:
             // config B 8 waves -> 982 us, 4 -> 1214, 2 -> 1890)

@@ -235,6 +235,11 @@ def test_slab_union_equals_full_frame(oracle):
         r.render_uniforms(u); r.wait()
         _check_stages(r, ref, exact_image=True, debug=False)
         parts.append(r.read_rgba8())
+        r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)  # depth-ordered emission inside a slab
+        r.render_uniforms(u); r.wait()
+        assert r.stats()["depth_ordered"] == 1
+        _check_stages(r, ref, exact_image=True, debug=False)
+        np.testing.assert_array_equal(r.read_rgba8(), parts[-1])
         r.destroy()
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), img)
     full.destroy()
