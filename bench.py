@@ -74,13 +74,13 @@ def pmc_traffic(stage, workload):
     return None, None
 
 
-def cpu_baseline(n_full, W, H, seed, sample_n):
+def cpu_baseline(n_full, W, H, seed, sample_n, records=None):
     """Times the CPU oracle (oracle/gs_oracle.c, OpenMP) on a bounded sample of the same workload."""
     from gsplat import synth
     from oracle import gs_oracle
     gs_oracle.build()
     n = min(sample_n, n_full)
-    splats = synth.bicycle_like(n, seed)
+    splats = synth.bicycle_like(n, seed) if records is None else records[:n]
     u = synth.orbit_camera(0, W, H).uniforms(W, H)
     cores = gs_oracle.get_num_threads()
     t0 = time.perf_counter()
@@ -88,9 +88,9 @@ def cpu_baseline(n_full, W, H, seed, sample_n):
     dt = time.perf_counter() - t0
     return {
         "value": 1.0 / dt, "unit": "frames/s (on the sample)", "cores": cores, "kind": "port",
-        "sample": "1 frame, first %d of %d gaussians of the numpy-seeded scene, same %dx%d orbit camera; "
+        "sample": "1 frame, first %d of %d gaussians of the %s, same %dx%d orbit camera; "
                   "%d intersections; CPU restatement of the reference pipeline (oracle/gs_oracle.c, OpenMP)"
-                  % (n, n_full, W, H, out["num_intersections"]),
+                  % (n, n_full, "numpy-seeded scene" if records is None else ".ply scene", W, H, out["num_intersections"]),
         "seconds": dt,
         "linear_extrapolation_full_scene": (1.0 / dt) * n / n_full,
     }
@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
+                    help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
     args = ap.parse_args()
 
     import numpy as np
@@ -171,7 +173,14 @@ def main():
     bounds = multigpu.slab_bounds(W, ts, world)  # tile-column slabs
     cols = (bounds[rank], bounds[rank + 1])
 
-    splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
+    ply_records = None
+    if args.ply:  # a real scene when the box has one (never the case offline)
+        ply_records = gsplat.PackedGaussians.from_ply(args.ply).gaussiansBuffer
+        N = cfg["n"] = int(ply_records.shape[0])
+        cfg["name"] = "%s (%d gaussians) @%dx%d" % (os.path.basename(args.ply), N, W, H)
+        splats = torch.from_numpy(ply_records).to(dev)
+    else:
+        splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
     flags = 0 if args.no_timing else _abi.GS_FLAG_TIMING
     stream = torch.cuda.current_stream(dev).cuda_stream
     pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
@@ -237,7 +246,7 @@ def main():
         line = {
             "metric": "frames/sec", "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "ply" if args.ply else "synthetic",
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
                        "parallelism": "tile-column slabs x%d + all-gather" % world if world > 1 else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
@@ -269,7 +278,7 @@ def main():
             line["stages"] = stages
             line["frame_us_device"] = round(st["frame_us_mean"], 2)
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(N, W, H, seed, args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(N, W, H, seed, args.cpu_sample, ply_records)
             line["copy_probe"] = copy_probe(dev)
             # the reference itself (WGSL on a WebGPU runtime, TypeScript host) cannot run on this box
             line["webgpu_baseline"] = "unavailable (no WebGPU runtime, no TypeScript toolchain, no network)"
