@@ -155,15 +155,17 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 /* Tuning / profiling knobs. */
 #define GS_OPT_BLEND_ABLATION 1  /* bits 0-2 PROFILING ONLY, break the image (1 skip the pixel loop, 2 gather from a cache-resident window,
                                     4 skip cull+loop); bits 3/4 pick another tile-16 blend kernel with identical results (8 = four-wave
-                                    workgroup per tile, 16 = one wave per whole tile; default = one wave per 8x8 quadrant)          */
+                                    workgroup per tile, 16 = one wave per whole tile; default = one wave per 8x8 quadrant);
+                                    bits 6/7 PROFILING ONLY (image intact): cap the quadrant kernel at 2 / 4 waves per SIMD;
+                                    bits 8-15: tile-column strip width of the quadrant kernel's XCD mapping (0 = automatic)     */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
 #define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
 #define GS_OPT_EMIT_ORDER 4      /* 1: the reference's gaussian-index emission order + sort by the full key (3-4 radix digits);
                                     0: depth-ordered pipeline: sort the visible GAUSSIANS by depth bucket, emit their instances
                                     in that order (work-balanced), sort the instances by tile only (2 digits);
-                                    2 (default): choose per frame from the previous frame's instance count (whole canvas and
-                                    many instances -> 0, slabs and small scenes -> 1).  Sorted keys/values, ranges and image
-                                    are identical in every mode.                                                          */
+                                    2 (default): choose per frame from the previous frame's instance count ((radix sweeps saved)
+                                    x instances >= 15 M -> 0, else 1).  Sorted keys/values, ranges and image are identical in
+                                    every mode.                                                                           */
 #define GS_OPT_UNFUSED 5         /* 1 (default): projection, scan and emission are three launches; 0: experimental single fused launch
                                     (identical results; measured slower in round 1)                                              */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
