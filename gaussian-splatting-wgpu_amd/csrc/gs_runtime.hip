@@ -47,6 +47,10 @@ struct gs_ctx {
     GsFrame frame{};
     uint32_t T = 0, passes = 0, key_bits = 0; // passes: 8-bit digits of the full key (reference-order pipeline)
     uint32_t tile_passes = 0, tile_bits = 0;  // digits of key/1000 (depth-ordered pipeline)
+    bool tile16 = false;                      // every tile id fits 16 bits: the depth-ordered instance sort moves u16 sort words
+    bool last_keys16 = false;                 // the last frame's sorted keys are u16 tile ids (GS_BUF_KEYS is rebuilt on demand)
+    uint32_t* keysG = nullptr;                // ... into this buffer
+    bool keysG_valid = false;
     int emit_order = 2;                       // GS_OPT_EMIT_ORDER: 0 depth-bucket order, 1 gaussian-index order (reference), 2 auto
     bool index_order = true;                  // what the frame being enqueued uses
     bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
@@ -111,8 +115,9 @@ GS_EXPORT int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
 
 static void free_kv(gs_ctx* c) {
     hipFree(c->keysA); hipFree(c->valsA); hipFree(c->keysB); hipFree(c->valsB); hipFree(c->keysU); hipFree(c->valsU);
-    hipFree(c->ctl_mem); hipFree(c->chunk_table);
-    c->keysA = c->valsA = c->keysB = c->valsB = c->keysU = c->valsU = nullptr;
+    hipFree(c->ctl_mem); hipFree(c->chunk_table); hipFree(c->keysG);
+    c->keysA = c->valsA = c->keysB = c->valsB = c->keysU = c->valsU = c->keysG = nullptr;
+    c->keysG_valid = false;
     c->chunk_table = nullptr;
     c->ctl_mem = nullptr;
 }
@@ -182,6 +187,7 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     const uint32_t tbits = bits_for((uint64_t)f.nty * f.ntx + f.ntx);
     c->tile_passes = (tbits + 7) / 8;
     c->tile_bits = (tbits + c->tile_passes - 1) / c->tile_passes;
+    c->tile16 = ((uint64_t)f.nty * f.ntx + f.ntx) < 0xFFFFull;
     if ((uint64_t)(f.ntx + 1) * (f.nty + 1) > GS_COUNT_MASK) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: canvas has too many tiles"); }
 
     hipDeviceProp_t prop;
@@ -339,8 +345,10 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
                        (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
         gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
-                                c->tile_bits, c->tile_passes, st);
+                                c->tile_bits, c->tile_passes, c->tile16, st);
     }
+    const bool keys16 = !by_index && c->tile16;
+    c->keysG_valid = false;
     if (debug) {
         if (!c->keysU) {
             HIP_TRY(hipMalloc((void**)&c->keysU, (size_t)c->capacity * 4));
@@ -355,12 +363,14 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
                        (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
     else
         gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, 1, c->sort_status, c->grid_persist, /*have_hist=*/true, nullptr, nullptr, st,
-                       &c->keysS, &c->valsS);
+                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, keys16 ? 0 : 1, c->sort_status, c->grid_persist, /*have_hist=*/true,
+                       nullptr, nullptr, st, &c->keysS, &c->valsS, keys16);
     c->last_passes = by_index ? c->passes : c->tile_passes;
     c->last_by_index = by_index;
+    c->last_keys16 = keys16;
     mark(c, 4);
-    gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, st); // streaming: 8 workgroups/CU
+    if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, st);
+    else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, st); // streaming: 8 workgroups/CU
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
     const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, c->tile_depth, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
@@ -438,7 +448,18 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
     case GS_BUF_VALUES_UNSORTED:
         if (!c->last_debug || !c->keysU) return fail(GS_ERR_NO_FRAME, "unsorted taps need gs_render_debug");
         *ptr = which == GS_BUF_KEYS_UNSORTED ? c->keysU : c->valsU; *bytes = I * 4; return GS_OK;
-    case GS_BUF_KEYS: *ptr = c->keysS; *bytes = I * 4; return GS_OK;
+    case GS_BUF_KEYS:
+        *bytes = I * 4;
+        if (!c->last_keys16) { *ptr = c->keysS; return GS_OK; }
+        if (!c->keysG_valid) { // the frame was sorted on 16-bit tile ids: rebuild tile*1000 + bucket once
+            if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+            if (!c->keysG) HIP_TRY(hipMalloc((void**)&c->keysG, (size_t)c->capacity * 4));
+            gs_launch_rebuild_keys((const uint16_t*)c->keysS, c->valsS, c->counts, (uint32_t)I, c->n, c->keysG, c->stream);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->keysG_valid = true;
+        }
+        *ptr = c->keysG;
+        return GS_OK;
     case GS_BUF_VALUES: *ptr = c->valsS; *bytes = I * 4; return GS_OK;
     case GS_BUF_RANGES: *ptr = c->ranges; *bytes = (uint64_t)c->T * 4; return GS_OK;
     case GS_BUF_RGBA8: *ptr = c->last_ext ? c->last_ext : (void*)c->rgba8; *bytes = px * 4; return GS_OK;

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
                                                                 const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
                                                                 const uint32_t* __restrict__ chunk_table, GsFrame f,
                                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ values,
-                                                                GsControl* ctl, uint32_t hist_bits, uint32_t hist_passes) {
+                                                                GsControl* ctl, uint32_t hist_bits, uint32_t hist_passes, uint32_t keys16) {
     __shared__ uint32_t s_off[4][64];
     __shared__ uint32_t s_hist[4][256]; // digit counts of the instance sort (digits of key/1000), flushed once per workgroup
     for (uint32_t k = threadIdx.x; k < 4 * 256; k += 256) (&s_hist[0][0])[k] = 0u;
@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
                 const uint32_t px = (xx < wmain) ? xa + xx : f.ntx;
                 const uint32_t py = (y_b & 0xFFFFu) + yy;
                 const uint32_t tile_id = py * f.ntx + px;
-                keys[x] = tile_id * 1000u + (y_b >> 16);
+                // the instance sort that follows only orders by tile id (the depth order is already there): with keys16 the
+                // sort word is stored alone, as 16 bits; the full key is rebuilt for the tap (gs_rebuild_keys_kernel)
+                if (keys16) reinterpret_cast<uint16_t*>(keys)[x] = (uint16_t)tile_id;
+                else keys[x] = tile_id * 1000u + (y_b >> 16);
                 values[x] = s_gid[w][lo];
                 // the instance sort that follows orders by digits of the tile id: count them here, where the key is
                 // in a register, instead of re-reading all keys in a histogram kernel
@@ -409,7 +412,58 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restri
     }
 }
 
+// The same over sorted 16-bit tile ids (depth-ordered pipeline): eight per 16-byte load.
+__global__ __launch_bounds__(256) void gs_ranges16_kernel(const uint16_t* __restrict__ tiles, const GsControl* ctl, uint32_t capacity,
+                                                           uint32_t T, uint32_t* __restrict__ ranges) {
+    uint32_t I = ctl->num_intersections;
+    if (I > capacity) I = capacity;
+    const uint64_t nchunks = (uint64_t)I / 8 + 1; // chunk c covers boundaries 8c .. 8c+7 (those <= I)
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += stride) {
+        const uint32_t j0 = (uint32_t)(c * 8);
+        uint32_t k[8];
+        if (j0 + 8 <= I) {
+            const uint4 q = *reinterpret_cast<const uint4*>(tiles + j0);
+            k[0] = q.x & 0xFFFFu; k[1] = q.x >> 16; k[2] = q.y & 0xFFFFu; k[3] = q.y >> 16;
+            k[4] = q.z & 0xFFFFu; k[5] = q.z >> 16; k[6] = q.w & 0xFFFFu; k[7] = q.w >> 16;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) k[i] = (j0 + i < I) ? tiles[j0 + i] : 0xFFFFu;
+        }
+        uint32_t prev = (j0 == 0) ? 0u : tiles[j0 - 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t j = j0 + i;
+            if (j > I) break;
+            const uint32_t cur = (j == I) ? T : k[i];
+            if (cur != prev || j == I) ranges_boundary(j, prev, cur, T, ranges);
+            prev = cur;
+        }
+    }
+}
+
+// GS_BUF_KEYS tap of a frame sorted on 16-bit tile ids: key = tile*1000 + depth bucket of the gaussian (the high bits of
+// its tile-count word), write_tile_ids.wgsl:31.
+__global__ __launch_bounds__(256) void gs_rebuild_keys_kernel(const uint16_t* __restrict__ tiles, const uint32_t* __restrict__ vals,
+                                                               const uint32_t* __restrict__ counts, uint32_t count, uint32_t n,
+                                                               uint32_t* __restrict__ keys) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t g = vals[i];
+        keys[i] = (uint32_t)tiles[i] * 1000u + (g < n ? counts[g] >> GS_COUNT_BITS : 0u);
+    }
+}
+
 // ---- host launchers --------------------------------------------------------------------------------
+void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(gs_ranges16_kernel, dim3(grid), dim3(256), 0, st, tiles, ctl, capacity, T, ranges);
+}
+void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t* keys,
+                            hipStream_t st) {
+    if (!count) return;
+    const uint32_t blocks = (count + 255u) / 256u;
+    hipLaunchKernelGGL(gs_rebuild_keys_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, tiles, vals, counts, count, n, keys);
+}
 uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
                     uint32_t* vkey, uint32_t* vval, uint32_t* chunk_table, uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
@@ -422,9 +476,9 @@ void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32
 uint64_t gs_emit_chunks(uint64_t capacity) { return (capacity >> EMIT_CHUNK_SHIFT) + 2; }
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                              const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
-                             uint32_t hist_bits, uint32_t hist_passes, hipStream_t st) {
+                             uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st) {
     hipLaunchKernelGGL(gs_emit_balanced_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, chunk_table, f, keys,
-                       values, ctl, hist_bits, hist_passes);
+                       values, ctl, hist_bits, hist_passes, keys16 ? 1u : 0u);
 }
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st) {

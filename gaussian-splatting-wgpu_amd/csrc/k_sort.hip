@@ -30,7 +30,7 @@
 // key/1000 (mode 1: the depth-ordered pipeline sorts instances by tile only, see gs_runtime.hip).
 struct SortDigits {
     uint32_t bits;    // bits per pass (<= 8)
-    uint32_t by_tile; // 0: word = key, 1: word = key / 1000
+    uint32_t by_tile; // 0: word = key, 1: word = key / 1000 (u16 tile-id keys are their own word: mode 0)
 };
 __device__ __forceinline__ uint32_t sort_digit(uint32_t key, uint32_t pass, const SortDigits& sd) {
     // pad keys (0xFFFFFFFF, only in a tile's tail) must keep the largest digit in every pass so that they rank last
@@ -79,16 +79,19 @@ struct SweepShared {
     uint32_t tile;
 };
 
-template <bool FULL>
-__device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, GsControl* ctl,
+// KT: the keys' type in memory.  uint16_t = the depth-ordered pipeline's instance arrays, whose sort word is the tile id
+// alone (< 65535; the full key tile*1000 + bucket is rebuilt only for the tap): 12 instead of 16 bytes moved per pair
+// and sweep.  Registers and LDS hold the widened word; pads (0xFFFFFFFF) exist only there.
+template <bool FULL, typename KT>
+__device__ __forceinline__ void sweep_tile(SweepShared& sh, const KT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                           KT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, GsControl* ctl,
                                            const uint32_t* __restrict__ hist, uint32_t pass, SortDigits sd, uint32_t* status,
                                            uint32_t tile, uint32_t valid, const uint32_t* __restrict__ aux_table,
                                            uint32_t* __restrict__ aux_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wbase = w * (64 * RS_ITEMS) + lane; // this lane's first slot in the tile
-    const uint32_t* kp = keys_in + (uint64_t)tile * RS_TILE + wbase;
+    const KT* kp = keys_in + (uint64_t)tile * RS_TILE + wbase;
     const uint32_t* vp = vals_in + (uint64_t)tile * RS_TILE + wbase;
 
     uint32_t key[RS_ITEMS];
@@ -200,15 +203,16 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const uint32_t* __re
             const uint32_t k = sh.keys[pos];
             const uint32_t g = sh.gbase[sort_digit(k, pass, sd)] + pos;
             const uint32_t pv = sh.vals[pos];
-            keys_out[g] = k;
+            keys_out[g] = (KT)k;
             vals_out[g] = pv;
             if (aux_out) aux_out[g] = aux_table[pv]; // last sweep of the gaussian-level sort: tile counts in sorted order
         }
     }
 }
 
-__global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+template <typename KT>
+__global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const KT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                             KT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                              GsControl* ctl, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t pass,
                                                              SortDigits sd, uint32_t* status, const uint32_t* __restrict__ aux_table,
@@ -240,8 +244,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void gs_sort_sweep_kernel(const uint
         const uint32_t tile = sh.tile;
         if (tile >= ntiles) break; // uniform: every thread read the same ticket
         const uint32_t valid = (n - tile * RS_TILE < RS_TILE) ? n - tile * RS_TILE : RS_TILE;
-        if (valid == RS_TILE) sweep_tile<true>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid, aux_table, aux_out);
-        else sweep_tile<false>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid, aux_table, aux_out);
+        if (valid == RS_TILE) sweep_tile<true, KT>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid, aux_table, aux_out);
+        else sweep_tile<false, KT>(sh, keys_in, vals_in, keys_out, vals_out, ctl, s_dbase, pass, sd, status, tile, valid, aux_table, aux_out);
         __syncthreads(); // LDS is reused by the next tile
     }
 }
@@ -253,10 +257,11 @@ uint32_t gs_sort_tiles(uint64_t capacity) { return (uint32_t)((capacity + RS_TIL
 // and status (passes * gs_sort_tiles(capacity) * 256 words) must have been zeroed by the caller.
 // have_hist: the caller already accumulated the digit counts into hist (the scan does it for the gaussian-level sort).
 // aux_table/aux_out (optional): the last sweep also writes aux_out[i] = aux_table[value_i] in sorted order.
+// keys16: the key arrays hold uint16_t sort words (by_tile must be 0 and have_hist true).
 void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
                     const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
                     uint32_t grid, bool have_hist, const uint32_t* aux_table, uint32_t* aux_out, hipStream_t st, uint32_t** out_keys,
-                    uint32_t** out_vals) {
+                    uint32_t** out_vals, bool keys16) {
     SortDigits sd;
     sd.bits = bits;
     sd.by_tile = by_tile;
@@ -265,9 +270,14 @@ void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t*
     uint32_t *ki = keysA, *vi = valsA, *ko = keysB, *vo = valsB;
     for (uint32_t p = 0; p < passes; ++p) {
         const bool last = (p + 1 == passes);
-        hipLaunchKernelGGL(gs_sort_sweep_kernel, dim3(grid), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, ctl, tickets + p, hist + p * 256, n_ptr,
-                           capacity, p, sd, status + p * per_pass, last ? aux_table : (const uint32_t*)nullptr,
-                           last ? aux_out : (uint32_t*)nullptr);
+        if (keys16)
+            hipLaunchKernelGGL(gs_sort_sweep_kernel<uint16_t>, dim3(grid), dim3(RS_THREADS), 0, st, (const uint16_t*)ki, vi, (uint16_t*)ko, vo, ctl,
+                               tickets + p, hist + p * 256, n_ptr, capacity, p, sd, status + p * per_pass,
+                               last ? aux_table : (const uint32_t*)nullptr, last ? aux_out : (uint32_t*)nullptr);
+        else
+            hipLaunchKernelGGL(gs_sort_sweep_kernel<uint32_t>, dim3(grid), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, ctl, tickets + p, hist + p * 256,
+                               n_ptr, capacity, p, sd, status + p * per_pass, last ? aux_table : (const uint32_t*)nullptr,
+                               last ? aux_out : (uint32_t*)nullptr);
         uint32_t* t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
     }
