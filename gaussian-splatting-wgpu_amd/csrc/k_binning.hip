@@ -330,32 +330,46 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
             const uint32_t stop = gend < c1 ? gend : c1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (uint32_t x = e + lane; x < stop; x += 64) {
-                uint32_t lo = 0; // largest j with s_off[j] <= x (absent members carry 0xFFFFFFFF)
+            // two output slots per lane and trip: their owner searches (six dependent LDS reads each) are independent,
+            // so the compiler interleaves them and half of that latency is hidden
+            for (uint32_t x0 = e + lane; x0 < stop; x0 += 128) {
+                const uint32_t x1 = x0 + 64;
+                const bool two = x1 < stop;
+                uint32_t lo0 = 0, lo1 = 0; // largest j with s_off[j] <= x (absent members carry 0xFFFFFFFF)
 #pragma unroll
                 for (int step = 32; step >= 1; step >>= 1) {
-                    const uint32_t mid = lo + step;
-                    if (mid < 64 && s_off[w][mid] <= x) lo = mid;
+                    const uint32_t m0 = lo0 + step, m1 = lo1 + step;
+                    const uint32_t o0 = s_off[w][m0 & 63u], o1 = s_off[w][m1 & 63u];
+                    if (m0 < 64 && o0 <= x0) lo0 = m0;
+                    if (m1 < 64 && o1 <= x1) lo1 = m1;
                 }
-                const uint32_t local = x - s_off[w][lo];
-                const uint32_t r = s_row[w][lo], y_b = s_yb[w][lo];
-                const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
-                const uint32_t wtot = wmain + alias;
-                const uint32_t yy = local / wtot, xx = local - yy * wtot;
-                const uint32_t px = (xx < wmain) ? xa + xx : f.ntx;
-                const uint32_t py = (y_b & 0xFFFFu) + yy;
-                const uint32_t tile_id = py * f.ntx + px;
-                // the instance sort that follows only orders by tile id (the depth order is already there): with keys16 the
-                // sort word is stored alone, as 16 bits; the full key is rebuilt for the tap (gs_rebuild_keys_kernel)
-                if (keys16) reinterpret_cast<uint16_t*>(keys)[x] = (uint16_t)tile_id;
-                else keys[x] = tile_id * 1000u + (y_b >> 16);
-                values[x] = s_gid[w][lo];
-                // the instance sort that follows orders by digits of the tile id: count them here, where the key is
-                // in a register, instead of re-reading all keys in a histogram kernel
-                atomicAdd(&s_hist[0][tile_id & hmask], 1u);
-                if (hist_passes > 1) atomicAdd(&s_hist[1][(tile_id >> hist_bits) & hmask], 1u);
-                if (hist_passes > 2) atomicAdd(&s_hist[2][(tile_id >> (2 * hist_bits)) & hmask], 1u);
-                if (hist_passes > 3) atomicAdd(&s_hist[3][(tile_id >> (3 * hist_bits)) & hmask], 1u);
+                auto put = [&](uint32_t x, uint32_t lo) {
+                    const uint32_t local = x - s_off[w][lo];
+                    const uint32_t r = s_row[w][lo], y_b = s_yb[w][lo];
+                    const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
+                    const uint32_t wtot = wmain + alias;
+                    // local / wtot with local < 2^22 and wtot < 2^16: the float quotient is off by at most one
+                    uint32_t yy = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)wtot));
+                    uint32_t xx = local - yy * wtot;
+                    if ((int32_t)xx < 0) { --yy; xx += wtot; }
+                    if (xx >= wtot) { ++yy; xx -= wtot; }
+                    const uint32_t px = (xx < wmain) ? xa + xx : f.ntx;
+                    const uint32_t py = (y_b & 0xFFFFu) + yy;
+                    const uint32_t tile_id = py * f.ntx + px;
+                    // the instance sort that follows only orders by tile id (the depth order is already there): with keys16
+                    // the sort word is stored alone, as 16 bits; the full key is rebuilt for the tap (gs_rebuild_keys_kernel)
+                    if (keys16) reinterpret_cast<uint16_t*>(keys)[x] = (uint16_t)tile_id;
+                    else keys[x] = tile_id * 1000u + (y_b >> 16);
+                    values[x] = s_gid[w][lo];
+                    // the instance sort orders by digits of the tile id: count them here, where the key is in a register,
+                    // instead of re-reading all keys in a histogram kernel
+                    atomicAdd(&s_hist[0][tile_id & hmask], 1u);
+                    if (hist_passes > 1) atomicAdd(&s_hist[1][(tile_id >> hist_bits) & hmask], 1u);
+                    if (hist_passes > 2) atomicAdd(&s_hist[2][(tile_id >> (2 * hist_bits)) & hmask], 1u);
+                    if (hist_passes > 3) atomicAdd(&s_hist[3][(tile_id >> (3 * hist_bits)) & hmask], 1u);
+                };
+                put(x0, lo0);
+                if (two) put(x1, lo1);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
