@@ -51,8 +51,9 @@ def algorithmic_bytes(st, W, H, T):
     }
 
 
-STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_kernel"],
-                 "sort": ["gs_sort_sweep_kernel"], "ranges": ["gs_ranges_kernel"],
+STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_balanced_kernel", "gs_emit_kernel"],
+                 "sort": ["gs_sort_sweep_kernel<unsigned short>", "gs_sort_sweep_kernel<unsigned int>", "gs_sort_sweep_kernel"],
+                 "ranges": ["gs_ranges16_kernel", "gs_ranges_kernel"],
                  "blend": ["gs_blend_quad_kernel", "gs_blend_wave_kernel", "gs_blend_kernel"]}
 
 

@@ -30,7 +30,7 @@ with open(out + "/pmc_summary.csv", "w") as w:
         w.write(k.replace(",", ";") + "," + str(n) + "," + ",".join("%.6g" % (sum(agg[k][c]) / len(agg[k][c])) if c in agg[k] else "" for c in names) + "\n")
 import json
 js = {"note": "mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them (tools/pmc_run.sh, 4 separate --pmc passes)",
-      "kernels": {k.split("<")[0].replace("void ", ""): {c: sum(v) / len(v) for c, v in agg[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")} for k in agg}}
+      "kernels": {k.replace("void ", "").replace("<false>", "").replace("<true>", "_exact"): {c: sum(v) / len(v) for c, v in agg[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")} for k in agg}}
 json.dump(js, open(out + "/pmc.json", "w"), indent=1)
 print(open(out + "/pmc_summary.csv").read())
 PY
