@@ -97,6 +97,41 @@ def cpu_baseline(n_full, W, H, seed, sample_n, records=None):
     }
 
 
+def pipelined_pass(gsplat, owner, W, H, ts, device, uniforms, args):
+    """K frames in flight: K-1 more contexts borrow the owner's splats (gs_share_splats) and the same K steps are rendered
+    round-robin, a context being waited for only when its buffers are needed again.  Reported beside `value` (which is the
+    reference's discipline, one frame in flight): the blend of frame k overlaps the binning and sort of frame k+1."""
+    K = args.frames_in_flight
+    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+    pg.numGaussians, pg.gaussiansBuffer = owner.numGaussians, None
+    rs = [owner] + [gsplat.Renderer(gsplat.Canvas(W, H), None, device, pg, ts, share_with=owner) for _ in range(K - 1)]
+    for r in rs[1:]:
+        if args.emit_order >= 0:
+            r.set_option(_OPT_EMIT_ORDER, args.emit_order)
+        if args.blend_ablation:
+            r.set_option(_OPT_BLEND_ABLATION, args.blend_ablation)
+    for k in range(args.warmup):
+        rs[k % K].render_uniforms(uniforms[k % 64])
+    for r in rs:
+        r.wait()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        r = rs[k % K]
+        if k >= K:
+            r.wait()
+        r.render_uniforms(uniforms[(args.warmup + k) % 64])
+    for r in rs:
+        r.wait()
+    dt = time.perf_counter() - t0
+    for r in rs[1:]:
+        r.destroy()
+    return {"frames_in_flight": K, "value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+            "note": "same frames, %d contexts sharing the resident splats rendered round-robin on their own streams" % K}
+
+
+_OPT_EMIT_ORDER, _OPT_BLEND_ABLATION = 4, 1  # gs_abi.h GS_OPT_EMIT_ORDER / GS_OPT_BLEND_ABLATION
+
+
 def copy_probe(dev, nbytes=512 << 20, iters=10):
     """Device-to-device copy of `nbytes` (outside the timed region): the practical HBM ceiling of this box, reported
     beside the 8 TB/s nominal peak the roofline fractions are quoted against."""
@@ -135,6 +170,9 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="N=1 only: after the timed region, a second pass with this many frames in flight (contexts sharing the "
+                         "splats, gs_share_splats) is reported as `pipelined`; 0 or 1 skips it.  `value` is always one frame in flight")
     ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
                     help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
     args = ap.parse_args()
@@ -278,6 +316,8 @@ def main():
                                                   "unit": "TFLOP/s", "frac": round(flops / (bus * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, 4)}
             line["stages"] = stages
             line["frame_us_device"] = round(st["frame_us_mean"], 2)
+        if world == 1 and args.frames_in_flight > 1:
+            line["pipelined"] = pipelined_pass(gsplat, r, W, H, ts, local_rank, uniforms, args)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(N, W, H, seed, args.cpu_sample, ply_records)
             line["copy_probe"] = copy_probe(dev)

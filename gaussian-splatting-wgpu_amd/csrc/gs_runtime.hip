@@ -80,6 +80,7 @@ struct gs_ctx {
     uint32_t* sort_status = nullptr;            // instance sort
     uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
     uint32_t* scounts = nullptr;                // tile-count words of the visible gaussians in depth-sorted order
+    bool scene_borrowed = false;                // gs_share_splats: scene_mem belongs to another context
     uint32_t last_passes = 0;
     bool last_by_index = true;
     uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
@@ -219,7 +220,8 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_kv(c);
-    hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
+    if (!c->scene_borrowed) hipFree(c->scene_mem);
+    hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb);
     if (c->h_ctl) hipHostFree(c->h_ctl);
@@ -231,23 +233,20 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     return GS_OK;
 }
 
-static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
-    hipFree(c->scene_mem); hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
+GS_EXPORT int32_t gs_wait(gs_ctx* c);
+// Frees the previous scene and per-gaussian work arrays, allocates the work arrays for n gaussians.
+static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n) {
+    if (!c->scene_borrowed) hipFree(c->scene_mem);
+    hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
     c->scounts = nullptr;
     c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
     c->vkeyA = c->vvalA = c->vkeyB = c->vvalB = nullptr;
+    c->scene_borrowed = false;
     c->n = (uint32_t)n;
     c->frame.n = (uint32_t)n;
     c->have_frame = false;
-    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and the records 256-byte aligned
-    const size_t bytes = np * 4 * 4 + (size_t)n * 256;
-    HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
-    char* p = (char*)c->scene_mem;
-    GsScene& s = c->scene;
-    s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
-    s.smax = (float*)p; p += np * 4;
-    s.rec = (float4*)p;
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
     HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->vkeyA, std::max<size_t>(np * 4, 256)));
@@ -257,12 +256,39 @@ static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     HIP_TRY(hipMalloc((void**)&c->scounts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
-    if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
-    HIP_TRY(hipGetLastError());
     uint64_t cap = c->cfg.max_intersections ? c->cfg.max_intersections : std::max<uint64_t>(4 * n, 1u << 22);
     cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
-    int32_t rc = alloc_kv(c, cap);
+    return alloc_kv(c, cap);
+}
+
+static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
+    int32_t rc = alloc_per_gaussian(c, n);
     if (rc != GS_OK) return rc;
+    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and the records 256-byte aligned
+    const size_t bytes = np * 4 * 4 + (size_t)n * 256;
+    HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
+    char* p = (char*)c->scene_mem;
+    GsScene& s = c->scene;
+    s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
+    s.smax = (float*)p; p += np * 4;
+    s.rec = (float4*)p;
+    if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_share_splats(gs_ctx* c, gs_ctx* owner) {
+    if (!c || !owner || c == owner) return fail(GS_ERR_INVALID_ARGUMENT, "gs_share_splats: needs two distinct contexts");
+    if (c->cfg.device != owner->cfg.device) return fail(GS_ERR_INVALID_ARGUMENT, "gs_share_splats: contexts are on different devices");
+    if (!owner->scene_mem) return fail(GS_ERR_NO_SCENE, "gs_share_splats: the owner holds no splats");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+    int32_t rc = alloc_per_gaussian(c, owner->n);
+    if (rc != GS_OK) return rc;
+    c->scene_mem = owner->scene_mem; // read-only during a frame; the owner must outlive this context
+    c->scene = owner->scene;
+    c->scene_borrowed = true;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GS_OK;
 }

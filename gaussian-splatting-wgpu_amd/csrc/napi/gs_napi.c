@@ -147,6 +147,19 @@ static napi_value js_upload(napi_env env, napi_callback_info info) {
     return rc == GS_OK ? NULL : throw_gs(env, rc);
 }
 
+/* shareSplats(handle, ownerHandle): render the owner's resident splats from a second context (gs_share_splats) */
+static napi_value js_share(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 2 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    gs_ctx* owner = unwrap(env, argv[1]);
+    if (!owner) return NULL;
+    int32_t rc = gs_share_splats(ctx, owner);
+    return rc == GS_OK ? NULL : throw_gs(env, rc);
+}
+
 /* renderSync(handle, uniforms160[, debug]) : enqueue + wait on the calling thread */
 static napi_value js_render_sync(napi_env env, napi_callback_info info) {
     size_t argc = 3;
@@ -352,7 +365,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"create", js_create},       {"destroy", js_destroy},         {"uploadSplats", js_upload},
         {"renderSync", js_render_sync}, {"renderAsync", js_render_async}, {"readRgba8", js_read_rgba8},
         {"readBuffer", js_read_buffer}, {"stats", js_stats},             {"slab", js_slab},
-        {"loadPly", js_load_ply},
+        {"loadPly", js_load_ply},    {"shareSplats", js_share},
     };
     for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
         napi_value f;

@@ -3,4 +3,4 @@ MI355X-native C ABI (include/gsplat/gs_abi.h).  The JavaScript host that drops i
 reference's TypeScript is in ../js; this package exists for tests, bench.py and torch.distributed."""
 from . import _abi, camera, synth  # noqa: F401
 from .camera import Camera  # noqa: F401
-from .renderer import Canvas, InteractiveCamera, PackedGaussians, Renderer  # noqa: F401
+from .renderer import Canvas, InteractiveCamera, PackedGaussians, PipelinedRenderer, Renderer  # noqa: F401

@@ -27,6 +27,7 @@ GS_OPT_UNFUSED = 5
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
+               "gs_share_splats",
                "gs_ply_load", "gs_ply_free", "gs_upload_ply",
                "gs_render", "gs_render_debug", "gs_render_to", "gs_wait", "gs_read_rgba8", "gs_read_buffer", "gs_device_ptr",
                "gs_get_stats", "gs_set_option", "gs_slab_width", "gs_assemble_slabs", "gs_sort_pairs_u32",
@@ -72,6 +73,7 @@ def load():
     L.gs_destroy.argtypes = [vp]
     L.gs_upload_splats.argtypes = [vp, vp, u64]
     L.gs_upload_splats_device.argtypes = [vp, vp, u64]
+    L.gs_share_splats.argtypes = [vp, vp]
     L.gs_ply_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(i32)]
     L.gs_ply_free.argtypes = [vp]
     L.gs_upload_ply.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(u64)]

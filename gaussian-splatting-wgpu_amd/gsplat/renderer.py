@@ -58,7 +58,9 @@ class InteractiveCamera:
 
 class Renderer:
     def __init__(self, canvas, interactiveCamera, device, gaussians, tileSize=16, *, flags=0, cols=None,
-                 max_intersections=0, stream=None):
+                 max_intersections=0, stream=None, share_with=None):
+        """share_with: another Renderer on the same device whose resident splats this one renders (gs_share_splats)
+        instead of uploading `gaussians` again."""
         self.canvas = canvas
         self.interactiveCamera = interactiveCamera
         self.device = int(device)
@@ -78,8 +80,11 @@ class Renderer:
         self._ctx = ctypes.c_void_p()
         check(self._L.gs_create(ctypes.byref(cfg), ctypes.byref(self._ctx)))
         self.flags = flags
-        buf = gaussians.gaussiansBuffer
-        if hasattr(buf, "data_ptr"):  # a device tensor: no PCIe copy
+        buf = gaussians.gaussiansBuffer if share_with is None else None
+        self._owner = share_with  # keeps the owner of borrowed splats alive
+        if share_with is not None:
+            check(self._L.gs_share_splats(self._ctx, share_with._ctx))
+        elif hasattr(buf, "data_ptr"):  # a device tensor: no PCIe copy
             check(self._L.gs_upload_splats_device(self._ctx, buf.data_ptr(), self.numGaussians))
         else:
             arr = np.ascontiguousarray(buf, dtype=np.float32)
@@ -159,3 +164,56 @@ class Renderer:
             self.destroy()
         except Exception:
             pass
+
+
+class PipelinedRenderer:
+    """K frames in flight: K contexts (one uploads the splats, the others borrow them) rendered round-robin, each on its
+    own stream with its own per-frame buffers, so frame k's blend overlaps frame k+1's binning and sort.  The reference
+    keeps one frame in flight (Renderer.animate awaits every stage, renderer.ts:394-587); results per frame are identical.
+    `render_uniforms` returns the slot used; `wait(slot)` / `read_rgba8(slot)` address a frame; `wait()` drains all."""
+
+    def __init__(self, canvas, interactiveCamera, device, gaussians, tileSize=16, *, frames_in_flight=2, **kw):
+        if frames_in_flight < 1:
+            raise ValueError("frames_in_flight must be >= 1")
+        first = Renderer(canvas, interactiveCamera, device, gaussians, tileSize, **kw)
+        self.renderers = [first] + [Renderer(canvas, interactiveCamera, device, gaussians, tileSize, share_with=first, **kw)
+                                    for _ in range(frames_in_flight - 1)]
+        self.canvas, self.interactiveCamera = canvas, interactiveCamera
+        self._next = 0
+        self._busy = [False] * frames_in_flight
+        self.numFrames = 0
+
+    def render_uniforms(self, uniforms):
+        slot = self._next
+        r = self.renderers[slot]
+        if self._busy[slot]:
+            r.wait()  # the frame this context rendered K steps ago must be complete before its buffers are reused
+        r.render_uniforms(uniforms)
+        self._busy[slot] = True
+        self._next = (slot + 1) % len(self.renderers)
+        self.numFrames += 1
+        return slot
+
+    def animate(self):
+        if not self.interactiveCamera.isDirty():
+            return None
+        cam = self.interactiveCamera.getCamera()
+        return self.render_uniforms(cam.uniforms(self.canvas.width, self.canvas.height))
+
+    def wait(self, slot=None):
+        for k, r in enumerate(self.renderers):
+            if (slot is None or slot == k) and self._busy[k]:
+                r.wait()
+                self._busy[k] = False
+
+    def read_rgba8(self, slot):
+        self.wait(slot)
+        return self.renderers[slot].read_rgba8()
+
+    def set_option(self, key, value):
+        for r in self.renderers:
+            r.set_option(key, value)
+
+    def destroy(self):
+        for r in reversed(self.renderers):  # borrowers first
+            r.destroy()

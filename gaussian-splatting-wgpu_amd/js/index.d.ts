@@ -28,7 +28,7 @@ export class PackedGaussians {
 }
 export class Renderer {
   canvas: CanvasLike; interactiveCamera: InteractiveCamera; numGaussians: number; tileSize: number; numIntersections: number; numFrames: number;
-  constructor(canvas: CanvasLike, interactiveCamera: InteractiveCamera, device: number | { ordinal: number; flags?: number }, gaussians: PackedGaussians, tileSize: number);
+  constructor(canvas: CanvasLike, interactiveCamera: InteractiveCamera, device: number | { ordinal: number; flags?: number; shareWith?: Renderer }, gaussians: PackedGaussians, tileSize: number);
   animate(): Promise<void>; destroy(): Promise<void>;
   renderUniforms(uniforms: Float32Array, debug?: boolean): void; readPixels(): Uint8Array; readBuffer(which: number): ArrayBuffer;
   stats(): { numGaussians: number; numVisible: number; numIntersections: number; numProcessed: number; numTiles: number; sortPasses: number; frames: number; frameUs: number; stageUs: number[] };

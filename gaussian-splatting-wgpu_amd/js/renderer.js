@@ -35,9 +35,14 @@ class Renderer {
     const n = loadNative();
     const ordinal = typeof device === 'number' ? device : ((device && device.ordinal) || 0);
     const flags = (device && device.flags) || 0;
+    // device.shareWith: another Renderer on the same device whose resident splats this one renders (gs_share_splats) -
+    // several renderers driven round-robin keep several frames in flight (the reference has one: every stage is awaited)
+    const owner = (device && device.shareWith) || null;
+    this.owner = owner; // keeps the owner alive
     if (!canvas || !(canvas.width > 0) || !(canvas.height > 0)) throw new Error('WebGPU context not found!'); // renderer.ts:108-111
     this.handle = n.create({ width: canvas.width, height: canvas.height, tileSize, device: ordinal, flags });
-    n.uploadSplats(this.handle, gaussians.gaussiansBuffer, this.numGaussians); // renderer.ts:130-137
+    if (owner) n.shareSplats(this.handle, owner.handle);
+    else n.uploadSplats(this.handle, gaussians.gaussiansBuffer, this.numGaussians); // renderer.ts:130-137
     this.uniforms = new Float32Array(40);
     this.autoSchedule = !(canvas.manual === true);
     if (this.autoSchedule) setImmediate(() => this.animate()); // requestAnimationFrame(() => this.animate()), renderer.ts:323

@@ -131,6 +131,11 @@ void gs_ply_free(void* records);
 int32_t gs_upload_ply(gs_ctx* ctx, const char* path, uint64_t* n);
 /* Same, from a device pointer (no PCIe copy). */
 int32_t gs_upload_splats_device(gs_ctx* ctx, const void* d_aos320, uint64_t n);
+/* `ctx` renders `owner`'s resident splats (same device; read-only during a frame) with its own stream and per-frame
+ * buffers: several contexts rendered round-robin keep several frames in flight, so one frame's blend (instruction-issue
+ * bound) overlaps the next frame's binning and sort (memory/latency bound).  The reference has one frame in flight
+ * (Renderer.animate awaits every stage, renderer.ts:394-587).  `owner` must outlive `ctx` and must not re-upload meanwhile. */
+int32_t gs_share_splats(gs_ctx* ctx, gs_ctx* owner);
 
 /* Replaces one Renderer.animate() frame (renderer.ts:349-593): enqueues the whole frame for the
  * 160-byte uniform block and returns without waiting for the device. */

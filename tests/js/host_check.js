@@ -51,6 +51,22 @@ async function main() {
     const keys = new Uint32Array(r.readBuffer(g.BUF.KEYS));
     await r.destroy();
     console.log(JSON.stringify({ frames, numIntersections: r.numIntersections, stats: st, nkeys: keys.length, key0: keys.length ? keys[0] : 0 }));
+  } else if (cmd === 'shared') {
+    // shared <records.bin> <n> <W> <H> <tile> <uniforms.bin>: a second renderer borrows the first one's splats
+    const rec = fs.readFileSync(process.argv[3]);
+    const n = parseInt(process.argv[4], 10), W = parseInt(process.argv[5], 10), H = parseInt(process.argv[6], 10), ts = parseInt(process.argv[7], 10);
+    const ub = fs.readFileSync(process.argv[8]);
+    const u = new Float32Array(ub.buffer.slice(ub.byteOffset, ub.byteOffset + 160));
+    const pg = g.PackedGaussians.fromRecords(rec.buffer.slice(rec.byteOffset, rec.byteOffset + rec.byteLength), n);
+    const ic = { isDirty() { return false; }, getCamera() { return null; } };
+    const a = new g.Renderer({ width: W, height: H, manual: true }, ic, { ordinal: 0 }, pg, ts);
+    const b = new g.Renderer({ width: W, height: H, manual: true }, ic, { ordinal: 0, shareWith: a }, pg, ts);
+    a.renderUniforms(u); b.renderUniforms(u);
+    const pa = a.readPixels(), pb = b.readPixels();
+    let same = pa.length === pb.length && pa.length === W * H * 4;
+    for (let i = 0; same && i < pa.length; ++i) same = pa[i] === pb[i];
+    await b.destroy(); await a.destroy();
+    console.log(JSON.stringify({ same, bytes: pa.length }));
   } else {
     throw new Error('unknown command ' + cmd);
   }

@@ -245,6 +245,35 @@ def test_slab_union_equals_full_frame(oracle):
     full.destroy()
 
 
+def test_frames_in_flight_match_sequential(oracle):
+    """gs_share_splats + PipelinedRenderer: three frames in flight over shared splats give the frames of a single context."""
+    import gsplat
+    from gsplat import _abi
+    n, W, H = 50000, 512, 288
+    s = scene(n)
+    us = [_uniforms(W, H, step=k) for k in range(7)]
+    seq = _mk(s, W, H)
+    want = []
+    for u in us:
+        seq.render_uniforms(u); seq.wait()
+        want.append(seq.read_rgba8())
+    pr = gsplat.PipelinedRenderer(gsplat.Canvas(W, H), None, 0, gsplat.PackedGaussians(s), 16, frames_in_flight=3)
+    slots = [pr.render_uniforms(u) for u in us[:3]]
+    got = {}
+    for k in range(3, len(us)):
+        got[k - 3] = pr.read_rgba8(slots[(k - 3) % 3])  # frame k-3 before its slot is reused
+        slots[(k - 3) % 3] = pr.render_uniforms(us[k])
+    for k in range(len(us) - 3, len(us)):
+        got[k] = pr.read_rgba8(slots[k % 3])
+    for k in range(len(us)):
+        np.testing.assert_array_equal(got[k], want[k])
+    ref = oracle.render(s, us[-1], W, H, 16, want_illcond=True)
+    d8 = np.abs(got[len(us) - 1].astype(np.int32) - ref["rgba8"].astype(np.int32))
+    assert d8[~ref["illcond"].astype(bool)].max(initial=0) <= 1
+    pr.destroy()
+    seq.destroy()
+
+
 import glob as _glob
 import os as _os
 

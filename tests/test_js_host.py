@@ -127,3 +127,17 @@ def test_renderer_animate_end_to_end(tmp_path, oracle):
     assert info["nkeys"] == ref["num_intersections"] and info["key0"] == int(ref["sorted_keys"][0])
     img = np.fromfile(out, dtype=np.uint8).reshape(H, W, 4)
     np.testing.assert_array_equal(img, ref["rgba8"])
+
+
+@pytest.mark.gpu
+def test_renderer_shares_splats(tmp_path):
+    """device.shareWith: a second Renderer borrows the first one's resident splats (gs_share_splats) and draws the same frame."""
+    from gsplat import synth
+    n, W, H, ts = 6000, 192, 128, 16
+    s = scene(n)
+    u = synth.orbit_camera(9, W, H).uniforms(W, H)
+    rec, ub = str(tmp_path / "rec.bin"), str(tmp_path / "u.bin")
+    s.tofile(rec)
+    u.tofile(ub)
+    info = _node("shared", rec, n, W, H, ts, ub)
+    assert info["same"] and info["bytes"] == W * H * 4
