@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-verify", action="store_true", help="N>1: skip the post-run check of the assembled frame against a whole-canvas render")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="N=1 only: after the timed region, a second pass with this many frames in flight (contexts sharing the "
                          "splats, gs_share_splats) is reported as `pipelined`; 0 or 1 skips it.  `value` is always one frame in flight")
@@ -221,7 +222,12 @@ def main():
     else:
         splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
     flags = 0 if args.no_timing else _abi.GS_FLAG_TIMING
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # N > 1: the frame, the all-gather and the assembly are ordered by ONE torch stream.  It must not be the legacy default
+    # stream: its handle is 0, which gs_config.stream reads as "create your own" - the context would then run unordered with
+    # the collective and the send buffer would be gathered before the blend has written it.
+    if world > 1:
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
+    stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else None
     pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
     pg.numGaussians, pg.gaussiansBuffer, pg.sphericalHarmonicsDegree = N, splats, 3
     r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags, cols=cols if world > 1 else None,
@@ -272,6 +278,24 @@ def main():
         dt = float(t.item())
     st = r.stats()
 
+    verified = None
+    if world > 1 and rank == 0 and not args.no_verify:
+        # outside the timed region: the assembled last frame must equal a whole-canvas render of the same camera on this GPU
+        # (the slabs only filter the key emission: byte-for-byte equality, tests/test_gpu_parity.py::test_slab_union...)
+        pgv = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+        pgv.numGaussians, pgv.gaussiansBuffer = N, None
+        full = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pgv, ts, share_with=r)
+        full.render_uniforms(uniforms[(args.warmup + args.steps - 1) % 64])
+        full.wait()
+        whole = torch.from_numpy(full.read_rgba8())
+        got = xch.image.cpu()
+        verified = bool(torch.equal(whole, got))
+        if not verified:
+            d = (whole != got).any(dim=2)
+            cols = torch.nonzero(d.any(dim=0)).flatten()
+            print("verify: %d differing pixels, columns %d..%d, slab pixel bounds %s" % (int(d.sum()), int(cols.min()), int(cols.max()), xch.pixels), file=sys.stderr, flush=True)
+        full.destroy()
+
     if world > 1:
         # whole-frame statistics are the sums over the slabs
         v = torch.tensor([st["num_visible"], st["num_intersections"], st["num_processed"]], dtype=torch.int64, device=dev)
@@ -292,6 +316,8 @@ def main():
                        "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),
                        "camera": "64-step orbit, moved every frame"},
         }
+        if verified is not None:
+            line["slab_frame_equals_single_gpu_frame"] = verified
         if not args.no_timing and st["frames_timed"]:
             ab = algorithmic_bytes(st, W, H, T)
             stages = {}

@@ -63,7 +63,9 @@ typedef struct gs_config {
     uint32_t col_begin, col_end;/* tile-column slab owned by this ctx, [begin,end); 0,0 = whole screen          */
     uint32_t flags;             /* GS_FLAG_*                                                                     */
     uint64_t max_intersections; /* capacity hint for the (key,value) arrays; 0 = derive from the scene         */
-    void* stream;               /* hipStream_t to run on; NULL = the ctx creates its own                        */
+    void* stream;               /* hipStream_t to run on; NULL = the ctx creates its own (so the legacy default stream,
+                                   whose handle is 0, cannot be passed: give the ctx a created stream when its work must be
+                                   ordered with other work, e.g. a collective)                                      */
 } gs_config;
 
 /* ---- per-frame statistics (the reference only console.logs these: renderer.ts:406-590) ------- */

@@ -103,3 +103,52 @@ def test_slab_ranks_on_one_gpu(tmp_path):
     mp.spawn(_gpu_worker, args=(3, port, 400, 208, 16, out), nprocs=3, join=True)
     ok = np.load(out)
     assert ok[0] == 1 and ok[1] == 1
+
+
+def _gpu_stream_worker(rank, world, port, W, H, ts, out):
+    """The flow of bench.py --gpus N: blend straight into the send buffer (gs_render_to), all-gather, device-side assembly,
+    all ordered by one created torch stream, several frames back to back without host waits in between."""
+    import torch
+    import torch.distributed as dist
+    import gsplat
+    from gsplat import multigpu, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # not the default stream: its handle 0 means "own stream" to gs_create
+    s = synth.bicycle_like(60000)
+    us = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(5)]
+    b = multigpu.slab_bounds(W, ts, world)
+    r = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, gsplat.PackedGaussians(s), ts, cols=(b[rank], b[rank + 1]),
+                        stream=torch.cuda.current_stream(dev).cuda_stream)
+    x = multigpu.SlabExchange(W, H, ts, world, rank, dev, renderer=r)
+    for u in us:  # no host synchronisation between the frames
+        r.render_uniforms(u, out_ptr=x.send.data_ptr())
+        x.exchange()
+        if rank == 0:
+            x.assemble()
+    r.wait()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    if rank == 0:
+        img = x.image.cpu().numpy()
+        full = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, gsplat.PackedGaussians(s), ts)
+        full.render_uniforms(us[-1])
+        full.wait()
+        np.save(out, np.array([int(np.array_equal(img, full.read_rgba8()))]))
+        full.destroy()
+    r.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_side_exchange_is_ordered_with_the_frame(tmp_path):
+    """bench.py's N>1 step on one GPU with two processes: the gathered, assembled LAST frame equals the whole-canvas frame
+    (it would be a stale or torn slab if the collective were not ordered after the blend)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + 11
+    mp.spawn(_gpu_stream_worker, args=(2, port, 640, 368, 16, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1
