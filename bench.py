@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="N>1: all-gather on a side stream, overlapped with the next frame (multigpu.OverlappedExchange; correct "
+                         "under gloo rehearsal but its RCCL timing could not be measured on a one-GPU box, so it is opt-in)")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the post-run check of the assembled frame against a whole-canvas render")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="N=1 only: after the timed region, a second pass with this many frames in flight (contexts sharing the "
@@ -242,14 +245,19 @@ def main():
         r.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
-    xch = None
+    xch = ovl = None
     if world > 1:
         xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, renderer=r)
+        if args.overlap_exchange:
+            ovl = multigpu.OverlappedExchange(xch, torch.cuda.current_stream(dev))
 
     def step(k):
         u = uniforms[k % 64]
         if world == 1:
             r.render_uniforms(u)
+        elif ovl is not None:
+            r.render_uniforms(u, out_ptr=ovl.send_ptr())  # blend writes straight into this frame's send buffer
+            ovl.submit(assemble=(rank == 0))               # all-gather on the side stream; assembles the previous frame
         else:
             r.render_uniforms(u, out_ptr=xch.send.data_ptr())  # blend writes straight into the send buffer
             xch.exchange()                                      # one RCCL all-gather of the slabs over xGMI
@@ -257,6 +265,8 @@ def main():
                 xch.assemble()
 
     def sync():
+        if ovl is not None:
+            ovl.finish(assemble=(rank == 0))
         r.wait()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -311,7 +321,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "ply" if args.ply else "synthetic",
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
-                       "parallelism": "tile-column slabs x%d + all-gather" % world if world > 1 else "single GPU",
+                       "parallelism": ("tile-column slabs x%d + all-gather%s" % (world, " overlapped with the next frame" if ovl is not None else ""))
+                       if world > 1 else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
                        "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),
                        "camera": "64-step orbit, moved every frame"},

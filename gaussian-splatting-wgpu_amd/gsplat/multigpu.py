@@ -49,24 +49,80 @@ class SlabExchange:
     def cols(self):
         return (self.bounds[self.rank], self.bounds[self.rank + 1])
 
-    def exchange(self):
-        """all-gather of the send buffers; every rank ends up with every slab."""
+    def exchange(self, send=None, gathered=None):
+        """all-gather of the send buffers (self.send -> self.gathered unless given); every rank ends up with every slab."""
         import torch.distributed as dist
+        send = self.send if send is None else send
+        gathered = self.gathered if gathered is None else gathered
         if self.world == 1:
-            self.gathered.copy_(self.send)
+            gathered.copy_(send)
         elif dist.get_backend() == "gloo":
-            parts = list(self.gathered.view(self.world, self.stride).unbind(0))
-            dist.all_gather(parts, self.send)
+            parts = list(gathered.view(self.world, self.stride).unbind(0))
+            dist.all_gather(parts, send)
         else:
-            dist.all_gather_into_tensor(self.gathered, self.send)
+            dist.all_gather_into_tensor(gathered, send)
 
-    def assemble(self):
+    def assemble(self, gathered=None):
         """Column slabs -> row-major frame (self.image)."""
-        if self.renderer is not None and self.gathered.is_cuda:
-            self.renderer.assemble(self.gathered.data_ptr(), self.bounds, self.stride, self.image.data_ptr())
+        gathered = self.gathered if gathered is None else gathered
+        if self.renderer is not None and gathered.is_cuda:
+            self.renderer.assemble(gathered.data_ptr(), self.bounds, self.stride, self.image.data_ptr())
         else:
             for g, (b, e) in enumerate(self.pixels):
                 w = e - b
-                slab = self.gathered[g * self.stride: g * self.stride + self.H * w * 4].view(self.H, w, 4)
+                slab = gathered[g * self.stride: g * self.stride + self.H * w * 4].view(self.H, w, 4)
                 self.image[:, b:e, :] = slab
         return self.image
+
+
+class OverlappedExchange:
+    """The all-gather of frame k runs on a side stream while frame k+1 is rendered: two send/gather buffer pairs, the blend of
+    frame k writes pair k%2, the collective of that pair waits for the blend's event, the assembly of frame k is queued on the
+    render stream after frame k+1 (its gather has had a whole frame to finish).  `finish()` assembles the last frame."""
+
+    def __init__(self, xch, render_stream):
+        torch = xch.torch
+        self.x, self.torch = xch, torch
+        self.render_stream = render_stream
+        self.comm_stream = torch.cuda.Stream(xch.device)
+        self.send = [xch.send, torch.zeros_like(xch.send)]
+        self.gathered = [xch.gathered, torch.zeros_like(xch.gathered)]
+        self.ev_render = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_gather = [None, None]
+        self.k = 0
+        self.unassembled = None
+
+    def send_ptr(self):
+        """Where the blend of the next frame must write; orders that blend after the collective that last read the buffer."""
+        slot = self.k & 1
+        if self.ev_gather[slot] is not None:
+            self.render_stream.wait_event(self.ev_gather[slot])
+        return self.send[slot].data_ptr()
+
+    def submit(self, assemble):
+        """Call after the frame was enqueued on the render stream."""
+        torch = self.torch
+        slot = self.k & 1
+        self.ev_render[slot].record(self.render_stream)
+        self.comm_stream.wait_event(self.ev_render[slot])
+        with torch.cuda.stream(self.comm_stream):
+            self.x.exchange(self.send[slot], self.gathered[slot])
+            ev = torch.cuda.Event()
+            ev.record(self.comm_stream)
+        self.ev_gather[slot] = ev
+        if assemble and self.unassembled is not None:
+            self._assemble(self.unassembled)
+        self.unassembled = slot
+        self.k += 1
+
+    def _assemble(self, slot):
+        self.render_stream.wait_event(self.ev_gather[slot])
+        self.x.assemble(self.gathered[slot])
+
+    def finish(self, assemble):
+        if self.unassembled is not None:
+            if assemble:
+                self._assemble(self.unassembled)
+            else:
+                self.render_stream.wait_event(self.ev_gather[self.unassembled])
+            self.unassembled = None

@@ -105,7 +105,7 @@ def test_slab_ranks_on_one_gpu(tmp_path):
     assert ok[0] == 1 and ok[1] == 1
 
 
-def _gpu_stream_worker(rank, world, port, W, H, ts, out):
+def _gpu_stream_worker(rank, world, port, W, H, ts, out, overlap):
     """The flow of bench.py --gpus N: blend straight into the send buffer (gs_render_to), all-gather, device-side assembly,
     all ordered by one created torch stream, several frames back to back without host waits in between."""
     import torch
@@ -124,11 +124,18 @@ def _gpu_stream_worker(rank, world, port, W, H, ts, out):
     r = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, gsplat.PackedGaussians(s), ts, cols=(b[rank], b[rank + 1]),
                         stream=torch.cuda.current_stream(dev).cuda_stream)
     x = multigpu.SlabExchange(W, H, ts, world, rank, dev, renderer=r)
+    ovl = multigpu.OverlappedExchange(x, torch.cuda.current_stream(dev)) if overlap else None
     for u in us:  # no host synchronisation between the frames
-        r.render_uniforms(u, out_ptr=x.send.data_ptr())
-        x.exchange()
-        if rank == 0:
-            x.assemble()
+        if ovl is not None:  # all-gather on a side stream, overlapped with the next frame
+            r.render_uniforms(u, out_ptr=ovl.send_ptr())
+            ovl.submit(assemble=(rank == 0))
+        else:
+            r.render_uniforms(u, out_ptr=x.send.data_ptr())
+            x.exchange()
+            if rank == 0:
+                x.assemble()
+    if ovl is not None:
+        ovl.finish(assemble=(rank == 0))
     r.wait()
     torch.cuda.synchronize(dev)
     dist.barrier()
@@ -144,11 +151,12 @@ def _gpu_stream_worker(rank, world, port, W, H, ts, out):
 
 
 @pytest.mark.gpu
-def test_device_side_exchange_is_ordered_with_the_frame(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_device_side_exchange_is_ordered_with_the_frame(tmp_path, overlap):
     """bench.py's N>1 step on one GPU with two processes: the gathered, assembled LAST frame equals the whole-canvas frame
     (it would be a stale or torn slab if the collective were not ordered after the blend)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "ok.npy")
     port = 29500 + (os.getpid() % 2000) + 11
-    mp.spawn(_gpu_stream_worker, args=(2, port, 640, 368, 16, out), nprocs=2, join=True)
+    mp.spawn(_gpu_stream_worker, args=(2, port + int(overlap), 640, 368, 16, out, overlap), nprocs=2, join=True)
     assert np.load(out)[0] == 1
