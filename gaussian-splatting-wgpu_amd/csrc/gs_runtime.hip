@@ -53,6 +53,7 @@ struct gs_ctx {
     bool keysG_valid = false;
     int emit_order = 2;                       // GS_OPT_EMIT_ORDER: 0 depth-bucket order, 1 gaussian-index order (reference), 2 auto
     bool index_order = true;                  // what the frame being enqueued uses
+    uint32_t debug_view = 0;                  // GS_OPT_DEBUG_VIEW
     bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
     uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
@@ -404,6 +405,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     if (walkers < 0) return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
     c->blend_walkers = (uint32_t)walkers;
     mark(c, 6);
+    if (c->debug_view) gs_launch_debug_view(c->ranges, f, c->debug_view, target, st); // developer views, after the timed stages
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     c->pending = true;
@@ -592,6 +594,7 @@ GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; return GS_OK;
     case GS_OPT_EMIT_ORDER: if (value < 0 || value > 2) break; c->emit_order = (int)value; return GS_OK;
     case GS_OPT_UNFUSED: c->unfused = (value != 0); return GS_OK;
+    case GS_OPT_DEBUG_VIEW: if (value < 0 || value > 4) break; c->debug_view = (uint32_t)value; return GS_OK;
     default: break;
     }
     return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: bad key/value %d/%lld", key, (long long)value);

@@ -597,6 +597,42 @@ __global__ __launch_bounds__(256) void gs_assemble_kernel(const uint32_t* __rest
     image[t] = slabs[slab_off + (uint64_t)y * w + (x - x0)];
 }
 
+// ---- the developer views left commented out in compute_tiles.wgsl:35-38,67-70 (GS_OPT_DEBUG_VIEW) ------------------
+// 1: last row/column of every tile in red; 2: list length / 1000 as grey; 3: pixel position gradient;
+// 4: list length / 100 in red and green.  Drawn over the finished frame; never part of the hot path.
+__global__ __launch_bounds__(256) void gs_debug_view_kernel(const uint32_t* __restrict__ ranges, GsFrame f, uint32_t view,
+                                                             uint32_t* __restrict__ rgba8) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint64_t)f.slab_w * f.height) return;
+    const uint32_t y = (uint32_t)(t / f.slab_w), x = f.px0 + (uint32_t)(t % f.slab_w);
+    const uint32_t tile = x / f.tile_size + (y / f.tile_size) * f.ntx;
+    const uint32_t start = tile > 0 ? ranges[tile - 1] : 0u, end = ranges[tile];
+    const float len = (float)(end - start);
+    float c[3];
+    if (view == 1u) {
+        if (x % f.tile_size != f.tile_size - 1u && y % f.tile_size != f.tile_size - 1u) return;
+        c[0] = 1.0f; c[1] = 0.0f; c[2] = 0.0f;
+    } else if (view == 2u) {
+        c[0] = c[1] = c[2] = len / 1000.0f;
+    } else if (view == 3u) {
+        c[0] = (float)x / (float)f.width; c[1] = (float)y / (float)f.height; c[2] = 0.0f;
+    } else {
+        c[0] = c[1] = len / 100.0f; c[2] = 0.0f;
+    }
+    uint32_t px = 0xFF000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float v = wg_min(wg_max(c[ch], 0.0f), 1.0f);
+        px |= (uint32_t)__builtin_floorf(v * 255.0f + 0.5f) << (8 * ch);
+    }
+    rgba8[t] = px;
+}
+void gs_launch_debug_view(const uint32_t* ranges, const GsFrame& f, uint32_t view, uint32_t* rgba8, hipStream_t st) {
+    const uint64_t total = (uint64_t)f.slab_w * f.height;
+    if (!total || !view) return;
+    hipLaunchKernelGGL(gs_debug_view_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, ranges, f, view, rgba8);
+}
+
 // ---- host launchers --------------------------------------------------------------------------------
 template <int TS>
 static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* gdata, const uint32_t* values, const uint32_t* ranges,

@@ -24,6 +24,7 @@ GS_OPT_PERSISTENT_GRID = 2
 GS_OPT_RESET_TIMING = 3
 GS_OPT_EMIT_ORDER = 4
 GS_OPT_UNFUSED = 5
+GS_OPT_DEBUG_VIEW = 6
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",

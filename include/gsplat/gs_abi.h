@@ -173,6 +173,9 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     2 (default): choose per frame from the previous frame's instance count ((radix sweeps saved)
                                     x instances >= 15 M -> 0, else 1).  Sorted keys/values, ranges and image are identical in
                                     every mode.                                                                           */
+#define GS_OPT_DEBUG_VIEW 6      /* the developer views commented out in compute_tiles.wgsl:35-38,67-70, drawn over the frame: 0 off,
+                                    1 tile borders (last row/column of every tile red), 2 list length/1000 as grey, 3 pixel
+                                    position gradient, 4 list length/100 in red+green                                    */
 #define GS_OPT_UNFUSED 5         /* 1 (default): projection, scan and emission are three launches; 0: experimental single fused launch
                                     (identical results; measured slower in round 1)                                              */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);

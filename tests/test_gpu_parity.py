@@ -245,6 +245,47 @@ def test_slab_union_equals_full_frame(oracle):
     full.destroy()
 
 
+def test_debug_views():
+    """GS_OPT_DEBUG_VIEW: the developer views left commented out in compute_tiles.wgsl:35-38,67-70."""
+    from gsplat import _abi
+    n, W, H, ts = 20000, 200, 120, 16
+    s, u = scene(n), _uniforms(W, H, step=2)
+    r = _mk(s, W, H, ts)
+    r.render_uniforms(u); r.wait()
+    plain = r.read_rgba8()
+    rg = r.read_buffer(_abi.GS_BUF_RANGES).astype(np.int64)
+    ln = np.diff(np.concatenate([[0], rg]))
+    ntx = (W + ts - 1) // ts
+    yy, xx = np.mgrid[0:H, 0:W]
+    per_px = ln[(xx // ts) + (yy // ts) * ntx].astype(np.float32)
+
+    def unorm(v):
+        return np.floor(np.clip(v, 0.0, 1.0).astype(np.float32) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+
+    r.set_option(_abi.GS_OPT_DEBUG_VIEW, 2)  # list length / 1000 as grey (:67)
+    r.render_uniforms(u); r.wait()
+    img = r.read_rgba8()
+    g = unorm(per_px / np.float32(1000.0))
+    np.testing.assert_array_equal(img[..., 0], g)
+    np.testing.assert_array_equal(img[..., 1], g)
+    np.testing.assert_array_equal(img[..., 3], 255)
+    r.set_option(_abi.GS_OPT_DEBUG_VIEW, 1)  # tile borders in red (:35-38)
+    r.render_uniforms(u); r.wait()
+    img = r.read_rgba8()
+    border = (xx % ts == ts - 1) | (yy % ts == ts - 1)
+    assert (img[border] == np.array([255, 0, 0, 255], dtype=np.uint8)).all()
+    np.testing.assert_array_equal(img[~border], plain[~border])
+    r.set_option(_abi.GS_OPT_DEBUG_VIEW, 4)  # list length / 100 in red and green (:70)
+    r.render_uniforms(u); r.wait()
+    img = r.read_rgba8()
+    np.testing.assert_array_equal(img[..., 0], unorm(per_px / np.float32(100.0)))
+    assert (img[..., 2] == 0).all()
+    r.set_option(_abi.GS_OPT_DEBUG_VIEW, 0)
+    r.render_uniforms(u); r.wait()
+    np.testing.assert_array_equal(r.read_rgba8(), plain)
+    r.destroy()
+
+
 def test_frames_in_flight_match_sequential(oracle):
     """gs_share_splats + PipelinedRenderer: three frames in flight over shared splats give the frames of a single context."""
     import gsplat
