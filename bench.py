@@ -320,6 +320,7 @@ def main():
             "metric": "frames/sec", "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "ply" if args.ply else "synthetic",
+            "frames_in_flight": 1,  # `value`: every frame is enqueued on one stream after the previous one (Renderer.animate's discipline)
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
                        "parallelism": ("tile-column slabs x%d + all-gather%s" % (world, " overlapped with the next frame" if ovl is not None else ""))
                        if world > 1 else "single GPU",
