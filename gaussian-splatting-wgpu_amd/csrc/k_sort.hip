@@ -76,6 +76,7 @@ struct SweepShared {
     uint32_t keys[RS_TILE];
     uint32_t vals[RS_TILE];
     uint32_t wsum[4]; // inclusive digit-total sums of the four waves that own the 256 digits
+    uint32_t tot[256]; // early digit counts of the tile
     uint32_t tile;
 };
 
@@ -102,8 +103,18 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const KT* __restrict
         else key[j] = (wbase + j * 64 < valid) ? kp[j * 64] : 0xFFFFFFFFu; // pads sort last and are never stored
     }
     for (uint32_t k = lane; k < 256; k += 64) sh.hist[w][k] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Early aggregate: the tile's digit counts are cheap (16 LDS atomics per thread) next to the ranking below, and they
+    // are all a successor needs from this tile.  Publishing them BEFORE the ranking puts the ranking time between "my
+    // aggregate is visible" and "I look at my predecessors'", so the look-back rarely finds an unpublished word.
+    if (tid < 256u) sh.tot[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) atomicAdd(&sh.tot[sort_digit(key[j], pass, sd)], 1u);
+    __syncthreads();
+    if (tid < 256u) {
+        const uint32_t c = sh.tot[tid]; // (pads only exist in the last tile, whose counts no tile reads)
+        st_agent(status + (uint64_t)tile * 256 + tid, (tile == 0 ? RS_PREFIX : RS_AGG) | c);
+    }
 
     // rank inside the wave: peers = lanes holding the same digit (8 ballots), order = (item, lane)
 #pragma unroll
@@ -142,10 +153,7 @@ __device__ __forceinline__ void sweep_tile(SweepShared& sh, const KT* __restrict
 
         // publish this tile's digit count, then walk back over the predecessors' words
         uint32_t* my = status + (uint64_t)tile * 256 + tid;
-        if (tile == 0) {
-            st_agent(my, RS_PREFIX | total);
-        } else {
-            st_agent(my, RS_AGG | total);
+        if (tile > 0) { // (the aggregate, or tile 0's prefix, was published before the ranking)
             // Walk back over the predecessors' words LB at a time: the loads of one round are independent and in
             // flight together, so a walk of k tiles costs ~k/LB L2 round trips instead of k (all resident
             // workgroups start together, so the first tiles of a launch walk back hundreds of tiles).
