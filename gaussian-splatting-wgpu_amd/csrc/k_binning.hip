@@ -20,7 +20,7 @@
 // ------------------------------------------------------------------------------------------------
 #define EMIT_CHUNK_SHIFT 10
 #define EMIT_CHUNK (1u << EMIT_CHUNK_SHIFT) // output slots one wave emits at a time in the balanced emission
-#define SCAN_ITEMS 16
+#define SCAN_ITEMS 24 // 24 576 counts per workgroup: 6.1 M gaussians are 249 workgroups, one residency round of the 256 CUs
 #define SCAN_THREADS 1024 // 16 waves: the look-back chain advances 64 workgroups per step, so fewer, larger workgroups finish sooner
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
