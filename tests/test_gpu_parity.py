@@ -202,6 +202,40 @@ def test_edge_cases(oracle):
     r.destroy()
 
 
+def test_non_finite_splats(oracle):
+    """Poisoned records (zero quaternion -> NaN conic, infinite scale, NaN position, NaN SH, huge opacity logit) must not fault
+    and must bin, sort and blend like the canonical semantics (NaN compares false, f32->i32 saturates, NaN -> 0)."""
+    from gsplat import _abi
+    n, W, H = 6000, 192, 128
+    s = scene(n).copy()
+    s[10, 8:12] = 0.0                      # |q| = 0: 0/0 in the rotation
+    s[11, 4:7] = np.float32(80.0)          # exp(80) overflows to +inf scales
+    s[12, 0] = np.float32(np.nan)          # NaN position
+    s[13, 16:19] = np.float32(np.nan)      # NaN SH DC
+    s[14, 12] = np.float32(1e30)           # sigmoid(+huge)
+    s[15, 12] = np.float32(-1e30)          # sigmoid(-huge)
+    s[16, 4:7] = np.float32(-200.0)        # exp(-200) underflows to 0 scales
+    s[17, 8:12] = np.float32(np.inf)       # inf/inf in the rotation
+    u = _uniforms(W, H, step=5)
+    ref = oracle.render(s, u, W, H, 16, want_illcond=True)
+    for flags in (_abi.GS_FLAG_EXACT_BLEND, 0):
+        r = _mk(s, W, H, 16, flags=flags)
+        for debug in (True, False):
+            r.render_uniforms(u, debug=debug); r.wait()
+            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_COUNTS), ref["tile_counts"])
+            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ref["sorted_keys"])
+            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), ref["sorted_values"])
+            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RANGES), ref["ranges"])
+            img = r.read_rgba8()
+            if flags:
+                np.testing.assert_array_equal(img, ref["rgba8"])
+            else:
+                ill = ref["illcond"].astype(bool)
+                d8 = np.abs(img.astype(np.int32) - ref["rgba8"].astype(np.int32))
+                assert d8[~ill].max(initial=0) <= 1
+        r.destroy()
+
+
 def test_capacity_growth(oracle):
     """A frame that overflows the (key,value) capacity is re-rendered after growing it."""
     from gsplat import _abi
