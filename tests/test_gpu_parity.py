@@ -236,6 +236,48 @@ def test_non_finite_splats(oracle):
         r.destroy()
 
 
+def test_reupload_and_two_contexts_in_threads(oracle):
+    """gs_upload_splats may be called again on a live context (smaller, then larger scene), and two contexts driven from two
+    host threads at once give their own frames (the ABI is thread-safe across contexts, gs_abi.h)."""
+    import threading
+    from gsplat import _abi
+    W, H = 256, 160
+    u = _uniforms(W, H, step=6)
+    sa, sb = scene(9000), scene(30000)[9000:]
+    ra = oracle.render(sa, u, W, H, 16)
+    rb = oracle.render(sb, u, W, H, 16)
+    r = _mk(sb, W, H, 16, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.render_uniforms(u); r.wait()
+    np.testing.assert_array_equal(r.read_rgba8(), rb["rgba8"])
+    arr = np.ascontiguousarray(sa, dtype=np.float32)
+    _abi.check(r._L.gs_upload_splats(r._ctx, arr.ctypes.data, arr.shape[0]))  # smaller scene into the same context
+    r.render_uniforms(u); r.wait()
+    np.testing.assert_array_equal(r.read_rgba8(), ra["rgba8"])
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ra["sorted_keys"])
+    arr = np.ascontiguousarray(sb, dtype=np.float32)
+    _abi.check(r._L.gs_upload_splats(r._ctx, arr.ctypes.data, arr.shape[0]))  # and a larger one again
+    r.render_uniforms(u); r.wait()
+    np.testing.assert_array_equal(r.read_rgba8(), rb["rgba8"])
+    r2 = _mk(sa, W, H, 16, flags=_abi.GS_FLAG_EXACT_BLEND)
+    out = {}
+
+    def work(name, rr, n_frames):
+        img = None
+        for _ in range(n_frames):
+            rr.render_uniforms(u); rr.wait()
+            img = rr.read_rgba8()
+        out[name] = img
+
+    ta = threading.Thread(target=work, args=("b", r, 12)), threading.Thread(target=work, args=("a", r2, 12))
+    for t in ta:
+        t.start()
+    for t in ta:
+        t.join()
+    np.testing.assert_array_equal(out["b"], rb["rgba8"])
+    np.testing.assert_array_equal(out["a"], ra["rgba8"])
+    r.destroy(); r2.destroy()
+
+
 def test_capacity_growth(oracle):
     """A frame that overflows the (key,value) capacity is re-rendered after growing it."""
     from gsplat import _abi
