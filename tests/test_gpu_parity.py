@@ -236,6 +236,27 @@ def test_non_finite_splats(oracle):
         r.destroy()
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_configs_exact(oracle, seed):
+    """Seeded random canvases (odd sizes), tile sizes, scene sizes, cameras and scale modifiers: every stage bit-equal."""
+    from gsplat import _abi, synth
+    rng = np.random.default_rng(1000 + seed)
+    ts = int(rng.choice([8, 16, 16, 32]))
+    W, H = int(rng.integers(33, 420)), int(rng.integers(17, 300))
+    n = int(rng.integers(1, 40000))
+    s = synth.bicycle_like(n, seed=synth.BASE_SEED + 50 + seed)
+    u = synth.orbit_camera(int(rng.integers(0, 64)), W, H, radius=float(rng.uniform(2.0, 9.0)), height=float(rng.uniform(-2.0, 3.0))).uniforms(W, H).copy()
+    u[39] = np.float32(rng.choice([0.25, 1.0, 1.0, 3.0]))  # scale_modifier
+    ref = oracle.render(s, u, W, H, ts)
+    r = _mk(s, W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.render_uniforms(u, debug=True); r.wait()
+    _check_stages(r, ref, exact_image=True)
+    r.set_option(_abi.GS_OPT_EMIT_ORDER, int(rng.integers(0, 3)))
+    r.render_uniforms(u); r.wait()
+    _check_stages(r, ref, exact_image=True, debug=False)
+    r.destroy()
+
+
 def test_reupload_and_two_contexts_in_threads(oracle):
     """gs_upload_splats may be called again on a live context (smaller, then larger scene), and two contexts driven from two
     host threads at once give their own frames (the ABI is thread-safe across contexts, gs_abi.h)."""
