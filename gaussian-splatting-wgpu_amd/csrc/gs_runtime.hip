@@ -544,7 +544,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
-        if (c->blend_walkers == 4) { // quadrant kernel: sum over tiles of the deepest walker
+        if (c->blend_walkers >= 4) { // 8x8-block walkers (4 per 16-tile, 16 per 32-tile): sum over tiles of the deepest walker
             std::vector<uint32_t> depth(c->T);
             if (hipMemcpy(depth.data(), c->tile_depth, (size_t)c->T * 4, hipMemcpyDeviceToHost) == hipSuccess)
                 for (uint32_t v : depth) out->num_processed += v;

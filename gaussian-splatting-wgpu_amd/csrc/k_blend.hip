@@ -412,12 +412,12 @@ __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restri
 // round-robin placement) so the three extra gathers of every record are normally L2 hits; placement
 // only affects speed.
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT>
+template <bool EXACT, int TS = 16>
 __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                             const uint32_t* __restrict__ ranges, GsFrame f,
                                                             uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
                                                             uint32_t* __restrict__ tile_depth, uint32_t dbg) {
-    constexpr int TS = 16;
+    constexpr uint32_t BPR = TS / 8, NB = BPR * BPR; // 8x8 pixel blocks per tile row / per tile (4 at tile 16, 16 at tile 32)
     __shared__ float4 sP0[64];
     __shared__ float4 sP1[64];
     __shared__ float4 sP2[64];
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     // of its record hit in that L2 (a placement hint only - correctness does not depend on it).  SW = 3 measured best
     // (config B: 1 -> 1002 us, 2 -> 993, 3 -> 932, 5 -> 945, 8 -> 970, 15 -> 983).
     const uint32_t b = blockIdx.x;
-    const uint32_t x = b & 7u, j = b >> 3, q = j & 3u, t = j >> 2;
+    const uint32_t x = b & 7u, j = b >> 3, q = j % NB, t = j / NB;
     const uint32_t SW = (dbg >> 8) & 0xffu;
     const uint32_t ns = (slab_tx + SW - 1) / SW; // strips in this slab
     if (x >= ns) return;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     if (end > f.capacity) end = f.capacity;
     const float c255 = (float)(1.0 / 255.0);
     const float Wf = (float)f.width, Hf = (float)f.height;
-    const uint32_t bx0 = tx * TS + (q & 1u) * 8u, by0 = ty * TS + (q >> 1) * 8u;
+    const uint32_t bx0 = tx * TS + (q % BPR) * 8u, by0 = ty * TS + (q / BPR) * 8u;
     const uint32_t gx = bx0 + (lane & 7), gy = by0 + (lane >> 3);
     const float pxf = (float)gx, pyf = (float)gy, bx0f = (float)bx0, by0f = (float)by0;
     const bool outside = !(gx < f.width && gy < f.height);
@@ -652,13 +652,15 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
     const uint4* g = (const uint4*)gdata;
     switch (f.tile_size) {
     case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1;
-    case 16: {
+    case 16:
+    case 32: {
         // ablation bit 3 forces the 4-wave kernel, bit 4 the single-wave kernel; default: whole-tile waves once
         // the launch has >= 4 tiles per SIMD (1024 SIMDs), else the 4-wave kernel (slabs, small canvases)
         // default: one single-wave workgroup per 8x8 quadrant; ablation bits force the others
         // (8 = 4-wave workgroup per tile, 16 = one wave per whole tile)
         const bool wave = (dbg & 16u) != 0;
-        if (!(dbg & (8u | 16u))) {
+        const bool t32 = f.tile_size == 32;
+        if (!(dbg & (8u | 16u)) || (t32 && !(dbg & 8u))) {
             // strip width: the widest of 3, 2, 1 tile columns that still spreads the slab's columns evenly over the 8 XCDs
             // (120 or 240 columns -> 3; a 60-column slab -> 2; 30- and 15-column slabs -> 1); GS_OPT_BLEND_ABLATION
             // bits 8..15 override it
@@ -680,20 +682,25 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
             }
             dbg = (dbg & 0xffu) | (SW << 8);
             const uint32_t wmax = widest(SW);
-            const uint32_t nblk = 32u * wmax * grid.y;
+            const uint32_t nblk = (t32 ? 128u : 32u) * wmax * grid.y;
             // PROFILING ONLY: bits 6/7 reserve dynamic LDS so that only 2 / 4 waves fit a SIMD (occupancy sensitivity:
             // config B 8 waves -> 982 us, 4 -> 1214, 2 -> 1890)
             const uint32_t pad = (dbg & 64u) ? 20480u - 3072u : (dbg & 128u) ? 10240u - 3072u : 0u;
+            if (t32) {
+                if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true, 32>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+                else hipLaunchKernelGGL((gs_blend_quad_kernel<false, 32>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+                return 16;
+            }
             if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
             else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
             return 4;
         }
+        if (t32) { launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; } // ablation bit 3: 1024-thread workgroup per tile
         if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; }
         if (exact) hipLaunchKernelGGL((gs_blend_wave_kernel<true>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
         else hipLaunchKernelGGL((gs_blend_wave_kernel<false>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
         return 0;
     }
-    case 32: launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1;
     default: return -1;
     }
 }

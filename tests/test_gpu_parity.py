@@ -103,7 +103,7 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
-@pytest.mark.parametrize("variant", [0, 8, 16, 32, 5 * 256])  # GS_OPT_BLEND_ABLATION: 0 = default (quadrant waves), 8 = 4-wave workgroup per tile, 16 = whole-tile wave, 32 = the other gather of the quadrant kernel, 5<<8 = strip width 5
+@pytest.mark.parametrize("variant", [0, 8, 16, 5 * 256])  # GS_OPT_BLEND_ABLATION: 0 = default (8x8-block waves), 8 = 4-wave workgroup per tile, 16 = whole-tile wave, 5<<8 = strip width 5
 @pytest.mark.parametrize("exact", [True, False])
 def test_blend_kernel_variants(oracle, variant, exact):
     from gsplat import _abi
@@ -115,6 +115,22 @@ def test_blend_kernel_variants(oracle, variant, exact):
     r.render_uniforms(u)
     r.wait()
     _check_stages(r, ref, exact_image=exact, debug=False)
+    r.destroy()
+
+
+@pytest.mark.parametrize("variant", [0, 8])  # tile 32: 0 = sixteen 8x8-block waves per tile (default), 8 = one 1024-thread workgroup per tile
+@pytest.mark.parametrize("exact", [True, False])
+def test_blend_kernel_variants_tile32(oracle, variant, exact):
+    from gsplat import _abi
+    n, W, H = 60000, 640, 368
+    s, u = scene(n), _uniforms(W, H, step=7)
+    ref = oracle.render(s, u, W, H, 32, want_illcond=not exact)
+    r = _mk(s, W, H, 32, flags=_abi.GS_FLAG_EXACT_BLEND if exact else 0)
+    r.set_option(_abi.GS_OPT_BLEND_ABLATION, variant)
+    r.render_uniforms(u)
+    r.wait()
+    _check_stages(r, ref, exact_image=exact, debug=False)
+    assert r.stats()["num_processed"] > 0
     r.destroy()
 
 
