@@ -161,8 +161,8 @@ int32_t gs_device_ptr(gs_ctx* ctx, int32_t which, void** d_ptr);
 int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 /* Tuning / profiling knobs. */
 #define GS_OPT_BLEND_ABLATION 1  /* bits 0-2 PROFILING ONLY, break the image (1 skip the pixel loop, 2 gather from a cache-resident window,
-                                    4 skip cull+loop); bits 3/4 pick another tile-16 blend kernel with identical results (8 = four-wave
-                                    workgroup per tile, 16 = one wave per whole tile; default = one wave per 8x8 quadrant);
+                                    4 skip cull+loop); bits 3/4 pick another blend kernel with identical results (8 = one workgroup
+                                    per tile, tiles 16 and 32; 16 = one wave per whole 16-tile; default = one wave per 8x8 block);
                                     bits 6/7 PROFILING ONLY (image intact): cap the quadrant kernel at 2 / 4 waves per SIMD;
                                     bits 8-15: tile-column strip width of the quadrant kernel's XCD mapping (0 = automatic)     */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
