@@ -10,8 +10,10 @@ a camera that moves every step along a fixed orbit, with the splats already resi
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  The per-stage device times come from hipEvents that the library
-records on its own stream inside the timed region (GS_FLAG_TIMING); the CPU oracle is timed on a
-bounded sample of the same workload on rank 0 at N=1 (a reported baseline, not a target).
+records on its own stream inside the timed region (GS_FLAG_TIMING).  After the timed region (N = 1) the
+last camera is rendered again in the other blend mode and with the reference's binning (self_check), and
+the CPU oracle renders ONE whole frame of the same scene and camera on the host cores: that is both the
+cpu_baseline (a reported baseline, not a target) and the check of the frame the bench timed.
 """
 import argparse
 import json
@@ -51,17 +53,32 @@ def algorithmic_bytes(st, W, H, T):
     }
 
 
+def moved_bytes(st, W, H, T, tile16):
+    """What THIS build's kernels read + write per frame (beside SURVEY 8(d)'s reference-equivalent figures): the depth-ordered
+    pipeline keeps 16-bit tile ids as instance sort words (12 instead of 16 bytes per pair and sweep, no histogram pass),
+    emission writes 6 bytes per instance, ranges read 2."""
+    N, Nv, I, Ip, p = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"]
+    if st.get("depth_ordered") and tile16:
+        return {"preprocess": 12 * (N - Nv) + 268 * Nv + 4 * N + 64 * Nv, "scan": 8 * N + (8 + 2 * 16 + 4 + 12) * Nv,
+                "emit": 40 * Nv + 6 * I, "sort": 12 * p * I, "ranges": 2 * I + 4 * T, "blend": 4 * I + 48 * Ip + 4 * W * H}
+    return None
+
+
 STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_balanced_kernel", "gs_emit_kernel"],
                  "sort": ["gs_sort_sweep_kernel<unsigned short>", "gs_sort_sweep_kernel<unsigned int>", "gs_sort_sweep_kernel"],
                  "ranges": ["gs_ranges16_kernel", "gs_ranges_kernel"],
                  "blend": ["gs_blend_quad_kernel", "gs_blend_wave_kernel", "gs_blend_kernel"]}
 
 
+PMC_FILE = os.path.join("profiles", "r02_pmc.json")
+
+
 def pmc_traffic(stage, workload):
-    """HBM bytes per launch of the stage's main kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc.json,
-    collected with tools/pmc_run.sh on the same workload).  MI355X_MICROARCH.md (HBM): bytes = (FETCH_SIZE + WRITE_SIZE)
-    * 1024, and on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads, so it is doubled."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    """HBM bytes per launch of the stage's main kernel.  NOT measured by this run: PMC counters need their own rocprofv3
+    passes (gpurun refuses them beside tracing), so the figure is replayed from the committed passes of tools/pmc_run.sh
+    on the same workload (PMC_FILE; the `source` key of the result says so).  MI355X_MICROARCH.md (HBM): bytes =
+    (FETCH_SIZE + WRITE_SIZE) * 1024, and on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads, so it is doubled."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None, None
     js = json.load(open(path))
@@ -71,31 +88,32 @@ def pmc_traffic(stage, workload):
         c = js["kernels"].get(k)
         if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, {"kernel": k, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
-                                                                       "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count for 16 B/lane reads)"}
+                                                                       "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count for 16 B/lane reads)",
+                                                                       "source": PMC_FILE + " (committed rocprofv3 --pmc passes of the same workload, not this run)"}
     return None, None
 
 
-def cpu_baseline(n_full, W, H, seed, sample_n, records=None):
-    """Times the CPU oracle (oracle/gs_oracle.c, OpenMP) on a bounded sample of the same workload."""
-    from gsplat import synth
+def cpu_baseline(host_scene, n_full, W, H, ts, uniforms, max_n):
+    """Times the CPU oracle (oracle/gs_oracle.c, OpenMP over the box's host cores) on ONE whole frame of the SAME scene the
+    GPU rendered (the device tensor copied to the host), same camera as the last timed frame.  Scenes above max_n gaussians
+    are cut to their first max_n (stated in `sample`) so that the default run stays within minutes."""
     from oracle import gs_oracle
     gs_oracle.build()
-    n = min(sample_n, n_full)
-    splats = synth.bicycle_like(n, seed) if records is None else records[:n]
+    n = min(max_n, n_full)
+    splats = host_scene[:n]
     cores = gs_oracle.get_num_threads()
-    frames = 3  # three cameras of the orbit: ~5-10 s of wall time on the GPU box's host cores
     t0 = time.perf_counter()
-    for k in range(frames):
-        out = gs_oracle.render(splats, synth.orbit_camera(k, W, H).uniforms(W, H), W, H, 16, want_f32=False)
-    dt = (time.perf_counter() - t0) / frames
-    return {
-        "value": 1.0 / dt, "unit": "frames/s (on the sample)", "cores": cores, "kind": "port",
-        "sample": "3 frames, first %d of %d gaussians of the %s, same %dx%d orbit camera; "
-                  "%d intersections; CPU restatement of the reference pipeline (oracle/gs_oracle.c, OpenMP)"
-                  % (n, n_full, "numpy-seeded scene" if records is None else ".ply scene", W, H, out["num_intersections"]),
+    out = gs_oracle.render(splats, uniforms, W, H, ts, want_f32=False)
+    dt = time.perf_counter() - t0
+    res = {
+        "value": 1.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": "1 whole frame of %s, %dx%d, the camera of the last timed step; %d intersections (reference binning); "
+                  "CPU restatement of the reference pipeline (oracle/gs_oracle.c, OpenMP, no early exit: the reference has none)"
+                  % ("the same scene, all %d gaussians" % n_full if n == n_full else "the FIRST %d of %d gaussians of the same scene" % (n, n_full),
+                     W, H, out["num_intersections"]),
         "seconds_per_frame": dt,
-        "linear_extrapolation_full_scene": (1.0 / dt) * n / n_full,
     }
+    return res, (out if n == n_full else None)
 
 
 def pipelined_pass(gsplat, owner, W, H, ts, device, uniforms, args):
@@ -105,8 +123,10 @@ def pipelined_pass(gsplat, owner, W, H, ts, device, uniforms, args):
     K = args.frames_in_flight
     pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
     pg.numGaussians, pg.gaussiansBuffer = owner.numGaussians, None
-    rs = [owner] + [gsplat.Renderer(gsplat.Canvas(W, H), None, device, pg, ts, share_with=owner) for _ in range(K - 1)]
+    rs = [owner] + [gsplat.Renderer(gsplat.Canvas(W, H), None, device, pg, ts, share_with=owner, flags=owner.flags & 1) for _ in range(K - 1)]
     for r in rs[1:]:
+        if args.tile_cull >= 0:
+            r.set_option(7, args.tile_cull)  # GS_OPT_TILE_CULL
         if args.emit_order >= 0:
             r.set_option(_OPT_EMIT_ORDER, args.emit_order)
         if args.blend_ablation:
@@ -131,6 +151,57 @@ def pipelined_pass(gsplat, owner, W, H, ts, device, uniforms, args):
 
 
 _OPT_EMIT_ORDER, _OPT_BLEND_ABLATION = 4, 1  # gs_abi.h GS_OPT_EMIT_ORDER / GS_OPT_BLEND_ABLATION
+_KEEP = {}
+
+
+def self_check(gsplat, _abi, r, W, H, ts, device, u_last, args):
+    """Outside the timed region (N = 1): the camera of the last timed step is rendered again (a) by the timed context, (b) by a
+    context in the other blend mode (EXACT <-> fused), (c) with the reference's rect binning and the other emission order;
+    (b) gives `exact_blend` (frames/s of the bit-exact mode over a short loop) and the fused-vs-exact pixel statistics,
+    (c) must give the same bytes as (a)/(b) in the same blend mode.  bench.py's CPU leg then compares the EXACT frame with the
+    oracle's frame of the same scene and camera."""
+    import numpy as np
+    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+    pg.numGaussians, pg.gaussiansBuffer = r.numGaussians, None
+    r.render_uniforms(u_last)
+    r.wait()
+    timed_img = r.read_rgba8()
+    other_flags = 0 if args.exact else _abi.GS_FLAG_EXACT_BLEND
+    o = gsplat.Renderer(gsplat.Canvas(W, H), None, device, pg, ts, flags=other_flags, share_with=r)
+    if args.tile_cull >= 0:
+        o.set_option(_abi.GS_OPT_TILE_CULL, args.tile_cull)
+    k = max(10, min(args.steps, 40))
+    us = [u_last] * 3
+    for u in us:
+        o.render_uniforms(u)
+        o.wait()
+    from gsplat import synth
+    orbit = [synth.orbit_camera(i, W, H).uniforms(W, H) for i in range(64)]
+    t0 = time.perf_counter()
+    for i in range(k):
+        o.render_uniforms(orbit[i % 64])
+    o.wait()
+    other_fps = k / (time.perf_counter() - t0)
+    o.render_uniforms(u_last)
+    o.wait()
+    other_img = o.read_rgba8()
+    exact_img, fused_img = (timed_img, other_img) if args.exact else (other_img, timed_img)
+    _KEEP["exact_frame"] = exact_img
+    # (c) reference binning + the reference's emission order, same blend mode as `o` (EXACT unless --exact)
+    o.set_option(_abi.GS_OPT_TILE_CULL, 0)
+    o.set_option(_abi.GS_OPT_EMIT_ORDER, 1)
+    o.render_uniforms(u_last)
+    o.wait()
+    ref_binning_same = bool(np.array_equal(o.read_rgba8(), other_img))
+    o.destroy()
+    d = np.abs(exact_img[..., :3].astype(np.int32) - fused_img[..., :3].astype(np.int32)).max(axis=2)
+    detail = {"fused_vs_exact_pixels_off_by_more_than_1_lsb": int((d > 1).sum()), "fused_vs_exact_max_lsb": int(d.max()),
+              "pixels": int(d.size), "tight_binning_frame_equals_reference_binning_frame": ref_binning_same}
+    ok = ref_binning_same and (d > 1).mean() <= 0.02
+    name = "fused_blend" if args.exact else "exact_blend"
+    return {"frame_verified": ok, "frame_verified_detail": detail,
+            name: {"value": other_fps, "unit": "frames/s", "steps": k, "note": "same scene and orbit, the other blend mode, short loop outside the timed region"}}
+
 
 
 def copy_probe(dev, nbytes=512 << 20, iters=10):
@@ -170,11 +241,13 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket stages with hipEvents")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-max", type=int, default=10_000_000, help="CPU baseline: render the whole scene on the host unless it has more gaussians than this")
+    ap.add_argument("--exact", action="store_true", help="time the bit-exact blend (GS_FLAG_EXACT_BLEND) instead of the default fused one")
+    ap.add_argument("--tile-cull", type=int, default=-1, help="GS_OPT_TILE_CULL override (1 = tight binning, default; 0 = the reference's rect binning)")
     ap.add_argument("--overlap-exchange", action="store_true",
                     help="N>1: all-gather on a side stream, overlapped with the next frame (multigpu.OverlappedExchange; correct "
                          "under gloo rehearsal but its RCCL timing could not be measured on a one-GPU box, so it is opt-in)")
-    ap.add_argument("--no-verify", action="store_true", help="N>1: skip the post-run check of the assembled frame against a whole-canvas render")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="N=1 only: after the timed region, a second pass with this many frames in flight (contexts sharing the "
                          "splats, gs_share_splats) is reported as `pipelined`; 0 or 1 skips it.  `value` is always one frame in flight")
@@ -225,7 +298,7 @@ def main():
         splats = torch.from_numpy(ply_records).to(dev)
     else:
         splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
-    flags = 0 if args.no_timing else _abi.GS_FLAG_TIMING
+    flags = (0 if args.no_timing else _abi.GS_FLAG_TIMING) | (_abi.GS_FLAG_EXACT_BLEND if args.exact else 0)
     # N > 1: the frame, the all-gather and the assembly are ordered by ONE torch stream.  It must not be the legacy default
     # stream: its handle is 0, which gs_config.stream reads as "create your own" - the context would then run unordered with
     # the collective and the send buffer would be gathered before the blend has written it.
@@ -236,8 +309,12 @@ def main():
     pg.numGaussians, pg.gaussiansBuffer, pg.sphericalHarmonicsDegree = N, splats, 3
     r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags, cols=cols if world > 1 else None,
                         stream=stream)
+    keep_scene = world == 1 and not args.no_cpu and ply_records is None  # the CPU baseline renders the same bits
+    host_scene = splats.cpu().numpy() if keep_scene else ply_records
     del splats, pg
     torch.cuda.empty_cache()
+    if args.tile_cull >= 0:
+        r.set_option(_abi.GS_OPT_TILE_CULL, args.tile_cull)
     if args.grid:
         r.set_option(_abi.GS_OPT_PERSISTENT_GRID, args.grid)
     if args.emit_order >= 0:
@@ -265,10 +342,17 @@ def main():
             if rank == 0:
                 xch.assemble()
 
+    trouble = {}
+
     def sync():
         if ovl is not None:
             ovl.finish(assemble=(rank == 0))
-        r.wait()
+        try:
+            r.wait()
+        except _abi.GsError as e:
+            if e.code != -9:  # GS_ERR_TRUNCATED: frames of this batch were rendered from truncated lists (capacity now grown)
+                raise
+            trouble["truncated"] = str(e)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -327,6 +411,7 @@ def main():
                        if world > 1 else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
                        "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),
+                       "tight_binning": bool(st["tight_binning"]), "blend_mode": "exact" if args.exact else "fused",
                        "camera": "64-step orbit, moved every frame"},
         }
         if verified is not None:
@@ -353,12 +438,30 @@ def main():
                 flops = 24.0 * 64.0 * st["num_evaluated"]
                 line["roofline"]["blend_valu"] = {"achieved": round(flops / (bus * 1e-6) / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                                                   "unit": "TFLOP/s", "frac": round(flops / (bus * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+            ntx_ = int(np.ceil(np.float32(W) / np.float32(ts)))
+            mb = moved_bytes(st, W, H, T, (T + ntx_) < 0xFFFF)
+            if mb:
+                for name in stages:
+                    stages[name]["moved_bytes_this_build"] = int(mb[name])
+                    stages[name]["moved_GBps"] = round(mb[name] / (st["stage_us_mean"][name] * 1e-6) / 1e9, 1) if st["stage_us_mean"][name] > 0 else 0.0
             line["stages"] = stages
             line["frame_us_device"] = round(st["frame_us_mean"], 2)
         if world == 1 and args.frames_in_flight > 1:
             line["pipelined"] = pipelined_pass(gsplat, r, W, H, ts, local_rank, uniforms, args)
+        line["capacity"] = {"entries": st["capacity"], "max_intersections_seen": st["max_intersections_seen"],
+                            "truncated_frames": st["truncated_frames"]}
+        if st["truncated_frames"] or trouble:
+            line["valid"] = False  # a timed frame was rendered from truncated lists: the number does not count
+            line["invalid_reason"] = trouble.get("truncated", "truncated frames")
+        if world == 1 and not args.no_verify:
+            line.update(self_check(gsplat, _abi, r, W, H, ts, local_rank, uniforms[(args.warmup + args.steps - 1) % 64], args))
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(N, W, H, seed, args.cpu_sample, ply_records)
+            u_last = uniforms[(args.warmup + args.steps - 1) % 64]
+            line["cpu_baseline"], ref = cpu_baseline(host_scene, N, W, H, ts, u_last, args.cpu_max)
+            if ref is not None and "exact_frame" in _KEEP:
+                same = bool(np.array_equal(_KEEP["exact_frame"], ref["rgba8"]))
+                line["frame_verified"] = same and line.get("frame_verified", True)
+                line["frame_verified_detail"]["exact_frame_equals_cpu_oracle_frame"] = same
             line["copy_probe"] = copy_probe(dev)
             # the reference itself (WGSL on a WebGPU runtime, TypeScript host) cannot run on this box
             line["webgpu_baseline"] = "unavailable (no WebGPU runtime, no TypeScript toolchain, no network)"

@@ -19,10 +19,11 @@ void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const ui
                              uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st);
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
-void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid, hipStream_t st);
+void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
+                        uint32_t* sticky, hipStream_t st);
 void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t* keys, hipStream_t st);
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                      hipStream_t st);
+                      uint32_t* sticky, hipStream_t st);
 uint32_t gs_sort_tiles(uint64_t capacity);
 void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
                     const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,

@@ -54,6 +54,8 @@ struct gs_ctx {
     int emit_order = 2;                       // GS_OPT_EMIT_ORDER: 0 depth-bucket order, 1 gaussian-index order (reference), 2 auto
     bool index_order = true;                  // what the frame being enqueued uses
     uint32_t debug_view = 0;                  // GS_OPT_DEBUG_VIEW
+    bool tile_cull = true;                    // GS_OPT_TILE_CULL: tight (opacity-aware) binning in gs_render / gs_render_to
+    bool last_tight = false;                  // the last frame used it
     bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
     uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
@@ -86,6 +88,10 @@ struct gs_ctx {
     bool last_by_index = true;
     uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
     GsControl* h_ctl = nullptr; // pinned
+    uint32_t* sticky = nullptr;   // device: [0] frames that overflowed, [1] fault, [2] largest I -- NOT in the per-frame memset (k_binning.hip fold_sticky)
+    uint32_t* h_sticky = nullptr; // pinned copy, refreshed by every frame
+    uint64_t max_I_seen = 0;      // largest instance count since GS_OPT_RESET_TIMING
+    uint64_t truncated_frames = 0; // frames that overflowed the capacity and were NOT the frame gs_wait could re-render
     // outputs
     uint32_t* ranges = nullptr;
     uint32_t* rgba8 = nullptr;
@@ -207,6 +213,10 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     HIP_TRY(hipHostMalloc((void**)&c->h_ctl, sizeof(GsControl), hipHostMallocDefault));
     memset(c->h_ctl, 0, sizeof(GsControl));
     HIP_TRY(hipMalloc((void**)&c->d_pxb, 65 * 4));
+    HIP_TRY(hipMalloc((void**)&c->sticky, 4 * 4));
+    HIP_TRY(hipMemset(c->sticky, 0, 4 * 4));
+    HIP_TRY(hipHostMalloc((void**)&c->h_sticky, 4 * 4, hipHostMallocDefault));
+    memset(c->h_sticky, 0, 4 * 4);
     if (cfg->flags & GS_FLAG_TIMING) {
         for (auto& row : c->ev)
             for (auto& e : row) HIP_TRY(hipEventCreate(&e));
@@ -224,8 +234,9 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
-    hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb);
+    hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky);
     if (c->h_ctl) hipHostFree(c->h_ctl);
+    if (c->h_sticky) hipHostFree(c->h_sticky);
     if (c->have_events)
         for (auto& row : c->ev)
             for (auto& e : row) hipEventDestroy(e);
@@ -396,8 +407,8 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     c->last_by_index = by_index;
     c->last_keys16 = keys16;
     mark(c, 4);
-    if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, st);
-    else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, st); // streaming: 8 workgroups/CU
+    if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st);
+    else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st); // streaming: 8 workgroups/CU
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
     const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, c->tile_depth, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
@@ -407,6 +418,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     mark(c, 6);
     if (c->debug_view) gs_launch_debug_view(c->ranges, f, c->debug_view, target, st); // developer views, after the timed stages
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_sticky, c->sticky, 4 * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     c->pending = true;
     c->have_frame = true;
@@ -436,24 +448,43 @@ GS_EXPORT int32_t gs_render_to(gs_ctx* c, const void* uniforms, void* d_rgba8) {
 GS_EXPORT int32_t gs_wait(gs_ctx* c) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_wait: null ctx");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    uint32_t dropped = 0; // frames enqueued before the last one that overflowed: their output was truncated and is gone
     for (int attempt = 0; attempt < 8; ++attempt) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->pending = false;
         if (!c->have_frame) return GS_OK;
-        if (c->h_ctl->fault) return fail(GS_ERR_DEVICE_FAULT, "a look-back spin exceeded its bound (fault word set)");
+        // the sticky words cover EVERY frame enqueued since the last gs_wait (the control block only the last one)
+        const uint32_t over_frames = c->h_sticky[0], fault_any = c->h_sticky[1];
+        const uint64_t max_I = c->h_sticky[2];
+        if (over_frames || fault_any || max_I) HIP_TRY(hipMemset(c->sticky, 0, 4 * 4)); // stream is idle
+        c->h_sticky[0] = c->h_sticky[1] = c->h_sticky[2] = 0;
+        if (max_I > c->max_I_seen) c->max_I_seen = max_I;
+        if (fault_any || c->h_ctl->fault) return fail(GS_ERR_DEVICE_FAULT, "a look-back spin exceeded its bound (fault word set)");
         const uint64_t I = c->h_ctl->num_intersections;
-        if (I <= c->capacity && !c->h_ctl->overflow) return GS_OK;
-        // the frame overflowed the (key,value) capacity: grow geometrically and render it again
-        uint64_t want = std::max<uint64_t>(I + I / 4, c->capacity * 2);
-        if (want >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "%llu intersections exceed the 2^30 limit", (unsigned long long)I);
+        const bool last_over = I > c->capacity || c->h_ctl->overflow;
+        if (attempt == 0 && over_frames > (last_over ? 1u : 0u)) dropped = over_frames - (last_over ? 1u : 0u);
+        const uint64_t need = std::max<uint64_t>(I, max_I);
+        if (!last_over && need <= c->capacity) break;
+        // a frame overflowed the (key,value) capacity: grow geometrically; re-render the last frame if it was one of them
+        if (need >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "%llu intersections exceed the 2^30 limit", (unsigned long long)need);
+        uint64_t want = std::max<uint64_t>(need + need / 4, c->capacity * 2);
+        want = std::min<uint64_t>(want, (1ull << 30) - 1);
         hipFree(c->keysU); hipFree(c->valsU); c->keysU = c->valsU = nullptr;
         int32_t rc = alloc_kv(c, want);
         if (rc != GS_OK) return rc;
+        if (!last_over) break;
+        if (attempt == 7) return fail(GS_ERR_CAPACITY, "capacity did not converge");
         c->frames--; // the re-render reuses the frame's slot in the event ring
         rc = enqueue_frame(c, c->last_u, c->last_debug, c->last_ext);
         if (rc != GS_OK) return rc;
     }
-    return fail(GS_ERR_CAPACITY, "capacity did not converge");
+    if (dropped) {
+        c->truncated_frames += dropped;
+        return fail(GS_ERR_TRUNCATED, "%u frame(s) enqueued before the last one overflowed the (key,value) capacity and were rendered from "
+                    "truncated lists; the capacity has been grown to %llu -- wait after every frame, or pass gs_config.max_intersections",
+                    dropped, (unsigned long long)c->capacity);
+    }
+    return GS_OK;
 }
 
 GS_EXPORT int32_t gs_slab_width(gs_ctx* c, uint32_t* px_begin, uint32_t* px_width) {
@@ -505,6 +536,16 @@ GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t s
     HIP_TRY(hipSetDevice(c->cfg.device));
     void* p = nullptr;
     uint64_t bytes = 0;
+    if (which == GS_BUF_BLOCK_MASKS && !c->last_tight) { // the reference's binning: the blend tests every block of the tile itself
+        bytes = std::min<uint64_t>(c->h_ctl->num_intersections, c->capacity) * 4;
+        if (written) *written = bytes;
+        if (!dst) return GS_OK;
+        if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
+        const uint32_t nb = (c->frame.tile_size / 8) * (c->frame.tile_size / 8);
+        const uint32_t all = nb >= 32 ? 0xFFFFFFFFu : (1u << nb) - 1u;
+        for (uint64_t i = 0; i < bytes / 4; ++i) ((uint32_t*)dst)[i] = all;
+        return GS_OK;
+    }
     int32_t rc = tap(c, which, &p, &bytes);
     if (rc != GS_OK) return rc;
     if (written) *written = bytes;
@@ -543,6 +584,10 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
     if (c->have_frame) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
+        out->capacity = c->capacity;
+        out->max_intersections_seen = std::max<uint64_t>(c->max_I_seen, c->h_ctl->num_intersections);
+        out->truncated_frames = c->truncated_frames;
+        out->tight_binning = c->last_tight ? 1u : 0u;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
         if (c->blend_walkers >= 4) { // 8x8-block walkers (4 per 16-tile, 16 per 32-tile): sum over tiles of the deepest walker
             std::vector<uint32_t> depth(c->T);
@@ -591,10 +636,11 @@ GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     switch (key) {
     case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
-    case GS_OPT_RESET_TIMING: c->timed_from = c->frames; return GS_OK;
+    case GS_OPT_RESET_TIMING: c->timed_from = c->frames; c->max_I_seen = 0; c->truncated_frames = 0; return GS_OK;
     case GS_OPT_EMIT_ORDER: if (value < 0 || value > 2) break; c->emit_order = (int)value; return GS_OK;
     case GS_OPT_UNFUSED: c->unfused = (value != 0); return GS_OK;
     case GS_OPT_DEBUG_VIEW: if (value < 0 || value > 4) break; c->debug_view = (uint32_t)value; return GS_OK;
+    case GS_OPT_TILE_CULL: c->tile_cull = (value != 0); return GS_OK;
     default: break;
     }
     return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: bad key/value %d/%lld", key, (long long)value);

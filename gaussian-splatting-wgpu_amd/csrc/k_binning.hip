@@ -28,6 +28,27 @@
 #define ST_PREFIX (2ull << 62)
 #define ST_MASK (3ull << 62)
 
+// Tile-count sums saturate at 2^32-1 instead of wrapping (saturating addition is associative, so every prefix is
+// min(true sum, 2^32-1)): a frame whose intersections exceed 32 bits then reports I = 0xFFFFFFFF > capacity and
+// gs_wait answers GS_ERR_CAPACITY instead of rendering a wrapped, truncated list as GS_OK.
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
+    const uint32_t s = a + b;
+    return s < a ? 0xFFFFFFFFu : s;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_sat(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if ((int)lane >= d) v = sat_add(v, t);
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_sat(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = sat_add(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
 // counts[] words are packed by the preprocess: tile count in the low 22 bits, depth bucket (the low part of
 // the sort key, write_tile_ids.wgsl:31) in the high 10.
 //   gather   : optional permutation; element k of the scan is counts[gather[k]] (depth-ordered pipeline)
@@ -71,7 +92,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
     uint32_t tsum = 0, tnz = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) { tsum += v[j] & GS_COUNT_MASK; tnz += ((v[j] & GS_COUNT_MASK) != 0u); }
-    const uint32_t incl = wave_incl_scan(tsum, lane);
+    const uint32_t incl = wave_incl_scan_sat(tsum, lane); // a thread's 24 counts (< 2^22 each) cannot wrap; wider sums saturate
     const uint32_t incl_nz = wave_incl_scan(tnz, lane);
     if (lane == 63) { s_wsum[w] = incl; s_wnz[w] = incl_nz; }
     __syncthreads();
@@ -79,11 +100,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
 #pragma unroll
     for (int k = 0; k < SCAN_WAVES; ++k) {
         const uint32_t t = s_wsum[k], z = s_wnz[k];
-        if (k < (int)w) { wave_excl += t; wave_excl_nz += z; }
-        block_total += t;
+        if (k < (int)w) { wave_excl = sat_add(wave_excl, t); wave_excl_nz += z; }
+        block_total = sat_add(block_total, t);
         block_nz += z;
     }
-    uint32_t run = wave_excl + incl - tsum;
+    uint32_t run = sat_add(wave_excl, incl - tsum); // incl - tsum: the exclusive in-wave prefix (exact unless incl saturated)
     uint32_t run_nz = wave_excl_nz + incl_nz - tnz;
 
     if (w == 0) {
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
                 const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
                 const uint32_t contrib = (lane <= first) ? (uint32_t)sv : 0u;
                 const uint32_t contrib_nz = (lane <= first) ? (uint32_t)((sv & ~ST_MASK) >> 32) : 0u;
-                excl += wave_sum(contrib);
+                excl = sat_add(excl, wave_sum_sat(contrib));
                 excl_nz += wave_sum(contrib_nz);
                 if (pmask) break;
                 look -= 64;
@@ -119,17 +140,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
         }
         if (lane == 0) {
             if (bid > 0)
-                st_agent64(&status[bid], ST_PREFIX | ((unsigned long long)(excl_nz + block_nz) << 32) | (unsigned long long)(excl + block_total));
+                st_agent64(&status[bid], ST_PREFIX | ((unsigned long long)(excl_nz + block_nz) << 32) | (unsigned long long)sat_add(excl, block_total));
             s_prefix[0] = excl;
             s_prefix[1] = excl_nz;
             if (write_totals && bid == nblocks - 1) {
                 ctl->num_visible = excl_nz + block_nz;
-                ctl->num_intersections = excl + block_total;
+                ctl->num_intersections = sat_add(excl, block_total);
             }
         }
     }
     __syncthreads();
-    run += s_prefix[0];
+    run = sat_add(run, s_prefix[0]);
     run_nz += s_prefix[1];
     if (vkey) { // ordered compaction of the elements with a non-zero tile count
         // ... and the digit histograms of the gaussian-level sort that follows (two 5-bit digits of the bucket):
@@ -398,8 +419,20 @@ __device__ __forceinline__ void ranges_boundary(uint32_t j, uint32_t lo, uint32_
 // Four consecutive sorted keys per thread (one 16-byte load + the neighbour before them), several
 // chunks in flight per thread: a pure streaming read.  Boundary j in [0, I] owns the tiles t with
 // tile[j-1] <= t < tile[j] (tile[-1] = 0, tile[I] = T).
+// sticky (optional): words that survive the per-frame memset of the control block.  Every frame folds its overflow / fault
+// flags and its instance count into them, so gs_wait also learns about frames that were enqueued BEFORE the last one
+// ([0] frames that overflowed the capacity, [1] a bounded spin gave up, [2] largest instance count seen).
+__device__ __forceinline__ void fold_sticky(const GsControl* ctl, uint32_t capacity, uint32_t* sticky) {
+    if (!sticky || blockIdx.x != 0 || threadIdx.x != 0) return;
+    const uint32_t I = ctl->num_intersections;
+    if (ctl->overflow || I > capacity) atomicAdd(&sticky[0], 1u);
+    if (ctl->fault) atomicOr(&sticky[1], 1u);
+    atomicMax(&sticky[2], I);
+}
+
 __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restrict__ keys, const GsControl* ctl, uint32_t capacity,
-                                                         uint32_t T, uint32_t* __restrict__ ranges) {
+                                                         uint32_t T, uint32_t* __restrict__ ranges, uint32_t* sticky) {
+    fold_sticky(ctl, capacity, sticky);
     uint32_t I = ctl->num_intersections;
     if (I > capacity) I = capacity;
     const uint64_t nchunks = (uint64_t)I / 4 + 1; // chunk c covers boundaries 4c .. 4c+3 (those <= I)
@@ -428,7 +461,8 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restri
 
 // The same over sorted 16-bit tile ids (depth-ordered pipeline): eight per 16-byte load.
 __global__ __launch_bounds__(256) void gs_ranges16_kernel(const uint16_t* __restrict__ tiles, const GsControl* ctl, uint32_t capacity,
-                                                           uint32_t T, uint32_t* __restrict__ ranges) {
+                                                           uint32_t T, uint32_t* __restrict__ ranges, uint32_t* sticky) {
+    fold_sticky(ctl, capacity, sticky);
     uint32_t I = ctl->num_intersections;
     if (I > capacity) I = capacity;
     const uint64_t nchunks = (uint64_t)I / 8 + 1; // chunk c covers boundaries 8c .. 8c+7 (those <= I)
@@ -469,8 +503,8 @@ __global__ __launch_bounds__(256) void gs_rebuild_keys_kernel(const uint16_t* __
 
 // ---- host launchers --------------------------------------------------------------------------------
 void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(gs_ranges16_kernel, dim3(grid), dim3(256), 0, st, tiles, ctl, capacity, T, ranges);
+                        uint32_t* sticky, hipStream_t st) {
+    hipLaunchKernelGGL(gs_ranges16_kernel, dim3(grid), dim3(256), 0, st, tiles, ctl, capacity, T, ranges, sticky);
 }
 void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t* keys,
                             hipStream_t st) {
@@ -501,6 +535,6 @@ void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* o
     hipLaunchKernelGGL(gs_emit_kernel, dim3(blocks), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, n_dev, f, keys, values, ctl);
 }
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                      hipStream_t st) {
-    hipLaunchKernelGGL(gs_ranges_kernel, dim3(grid), dim3(256), 0, st, keys, ctl, capacity, T, ranges);
+                      uint32_t* sticky, hipStream_t st) {
+    hipLaunchKernelGGL(gs_ranges_kernel, dim3(grid), dim3(256), 0, st, keys, ctl, capacity, T, ranges, sticky);
 }

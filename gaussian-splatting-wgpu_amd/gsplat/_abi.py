@@ -17,7 +17,7 @@ GS_FLAG_TIMING = 0x4
 GS_STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "blend")
 
 (GS_BUF_TILE_COUNTS, GS_BUF_TILE_OFFSETS, GS_BUF_GAUSSIAN_DATA, GS_BUF_KEYS_UNSORTED, GS_BUF_VALUES_UNSORTED, GS_BUF_KEYS,
- GS_BUF_VALUES, GS_BUF_RANGES, GS_BUF_RGBA8, GS_BUF_RGB_F32) = range(10)
+ GS_BUF_VALUES, GS_BUF_RANGES, GS_BUF_RGBA8, GS_BUF_RGB_F32, GS_BUF_BLOCK_MASKS) = range(11)
 
 GS_OPT_BLEND_ABLATION = 1
 GS_OPT_PERSISTENT_GRID = 2
@@ -25,6 +25,7 @@ GS_OPT_RESET_TIMING = 3
 GS_OPT_EMIT_ORDER = 4
 GS_OPT_UNFUSED = 5
 GS_OPT_DEBUG_VIEW = 6
+GS_OPT_TILE_CULL = 7
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
@@ -46,7 +47,9 @@ class GsStats(ctypes.Structure):
     _fields_ = [("num_gaussians", ctypes.c_uint64), ("num_visible", ctypes.c_uint64), ("num_intersections", ctypes.c_uint64),
                 ("num_processed", ctypes.c_uint64), ("num_tiles", ctypes.c_uint32), ("sort_passes", ctypes.c_uint32),
                 ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float),
-                ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32), ("depth_ordered", ctypes.c_uint32), ("num_evaluated", ctypes.c_uint64)]
+                ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32), ("depth_ordered", ctypes.c_uint32), ("num_evaluated", ctypes.c_uint64),
+                ("capacity", ctypes.c_uint64), ("max_intersections_seen", ctypes.c_uint64), ("truncated_frames", ctypes.c_uint64),
+                ("tight_binning", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
 
 class GsError(RuntimeError):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 /* ---- status codes (every function returns one; message via gs_last_error) ------------------ */
 #define GS_OK 0
@@ -34,6 +34,9 @@ extern "C" {
 #define GS_ERR_NO_FRAME (-6)         /* read-back before any gs_render                              */
 #define GS_ERR_DEVICE_FAULT (-7)     /* an in-kernel bounded spin gave up (decoupled look-back)     */
 #define GS_ERR_CAPACITY (-8)         /* intersections exceed the hard limit (2^30, radix_sort.wgsl:220-221) */
+#define GS_ERR_TRUNCATED (-9)        /* gs_wait: a frame enqueued BEFORE the last one overflowed the (key,value) capacity; its
+                                        output came from truncated lists and cannot be re-rendered (the last frame is complete and
+                                        the capacity has been grown)                                                          */
 
 /* ---- byte layouts fixed by the reference ------------------------------------------------------
  * splat record   320 B  ply.ts:190-198 / process_gaussians.wgsl:1-7
@@ -94,6 +97,13 @@ typedef struct gs_stats {
     uint32_t frames_timed;        /* frames the means cover                                    */
     uint32_t depth_ordered;       /* 1 if the last frame used the depth-ordered pipeline (GS_OPT_EMIT_ORDER)   */
     uint64_t num_evaluated;       /* blend: (8x8 pixel block, entry) pairs evaluated after the block cull */
+    uint64_t capacity;            /* entries the (key,value) arrays hold now                                  */
+    uint64_t max_intersections_seen; /* largest I of any frame since GS_OPT_RESET_TIMING (as of the last gs_wait) */
+    uint64_t truncated_frames;    /* frames since GS_OPT_RESET_TIMING that overflowed the capacity and could not be re-rendered
+                                     (only possible when several frames are enqueued per gs_wait)                 */
+    uint32_t tight_binning;       /* 1 if the last frame used the opacity-aware (tight) binning of the product path: its
+                                     instance lists are then a subset of the reference's (GS_OPT_TILE_CULL)             */
+    uint32_t reserved0;
 } gs_stats;
 
 /* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */
@@ -107,7 +117,9 @@ enum {
     GS_BUF_VALUES = 6,        /* u32[I]     sorted gaussianIDBuffer                            */
     GS_BUF_RANGES = 7,        /* u32[T]     rangesBuffer                                       */
     GS_BUF_RGBA8 = 8,         /* u8[H][Wslab][4] renderTarget (rgba8unorm), this ctx's slab    */
-    GS_BUF_RGB_F32 = 9        /* f32[H][Wslab][3] (GS_FLAG_F32_TAP)                            */
+    GS_BUF_RGB_F32 = 9,       /* f32[H][Wslab][3] (GS_FLAG_F32_TAP)                            */
+    GS_BUF_BLOCK_MASKS = 10   /* u32[I]     per sorted instance: one bit per 8x8 pixel block of its tile (row-major, tile_size/8
+                                 per row) the blend evaluates it for; all blocks when the frame did not use tight binning  */
 };
 
 typedef struct gs_ctx gs_ctx;
@@ -148,7 +160,9 @@ int32_t gs_render_debug(gs_ctx* ctx, const void* uniforms160);
  * (u8[height][slab_width][4]); used to render into a collective's send buffer. */
 int32_t gs_render_to(gs_ctx* ctx, const void* uniforms160, void* d_rgba8);
 /* Blocks until the frame is complete (the reference awaits onSubmittedWorkDone 8x per frame).
- * Reports device-side faults; grows the (key,value) capacity and re-renders if the frame overflowed. */
+ * Reports device-side faults; grows the (key,value) capacity and re-renders if the frame overflowed.  When several
+ * frames were enqueued since the last gs_wait and an EARLIER one overflowed, that frame cannot be re-rendered: the
+ * capacity is grown for the following frames and GS_ERR_TRUNCATED is returned (the last frame is complete). */
 int32_t gs_wait(gs_ctx* ctx);
 
 /* Replaces the blit to the canvas (render.wgsl, renderer.ts:549-574): copies the finished rgba8
@@ -178,6 +192,12 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     position gradient, 4 list length/100 in red+green                                    */
 #define GS_OPT_UNFUSED 5         /* 1 (default): projection, scan and emission are three launches; 0: experimental single fused launch
                                     (identical results; measured slower in round 1)                                              */
+#define GS_OPT_TILE_CULL 7       /* 1 (default): gs_render / gs_render_to bin TIGHTLY: an instance (gaussian, tile) is emitted only if
+                                    some pixel of the tile can reach alpha >= 1/255 (conservative test, so no output bit changes:
+                                    compute_tiles.wgsl:60-63 skips such an entry on every pixel), and carries a mask of the 8x8 pixel
+                                    blocks it can touch.  GS_BUF_KEYS / VALUES / RANGES / TILE_COUNTS of such a frame describe that
+                                    subset.  0: the reference's binning (every tile of the 3-sigma rect, process_gaussians.wgsl:74-86)
+                                    as gs_render_debug always uses.                                                              */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
 /* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
 int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);

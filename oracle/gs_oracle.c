@@ -483,6 +483,52 @@ GSO_API void gso_blend(const uint32_t* gdata, const uint32_t* values, const uint
         }
 }
 
+/*
+ * Checker for the product path's opacity-aware binning (DESIGN.md "tight binning"): for every instance
+ * (key, value) of a key list, one bit per 8x8 pixel block of the instance's tile (row-major, ts/8 blocks per
+ * tile row; a single bit at ts = 8) telling whether ANY in-canvas pixel of that block passes the reference's
+ * `power <= 0 && alpha >= 1/255` test (compute_tiles.wgsl:57-63) under the canonical arithmetic of gso_blend.
+ * An instance whose mask is 0 can never change a pixel (cond = 0 on every pixel), so a renderer may drop it
+ * without changing any output bit.  Tiles >= T (rows/columns one past the grid) give mask 0:
+ * compute_ranges ignores them.  Not part of the reference: it only exists to verify what the HIP path dropped.
+ */
+GSO_API void gso_instance_masks(const uint32_t* gdata, const uint32_t* keys, const uint32_t* values, uint64_t n,
+                                uint32_t W, uint32_t H, uint32_t ts, uint32_t* masks) {
+    const uint32_t ntx = ceil_div_tiles(W, ts), nty = ceil_div_tiles(H, ts);
+    const uint32_t T = ntx * nty, bpr = ts / 8;
+    const float c255 = (float)(1.0 / 255.0);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const uint32_t tile = keys[i] / 1000u;
+        uint32_t m = 0;
+        if (tile < T) {
+            const uint32_t tx = tile % ntx, ty = tile / ntx;
+            const uint32_t* o = gdata + (size_t)values[i] * GDATA_STRIDE_W;
+            f32bits q;
+            q.u = o[0]; float uvx = q.f;
+            q.u = o[1]; float uvy = q.f;
+            q.u = o[4]; float cx = q.f;
+            q.u = o[5]; float cy = q.f;
+            q.u = o[6]; float cz = q.f;
+            q.u = o[11]; float op = q.f;
+            const float gxy0 = uvx * (float)W, gxy1 = uvy * (float)H;
+            for (uint32_t ly = 0; ly < ts; ++ly)
+                for (uint32_t lx = 0; lx < ts; ++lx) {
+                    const uint32_t gx = tx * ts + lx, gy = ty * ts + ly;
+                    if (gx >= W || gy >= H) continue;
+                    const uint32_t bit = (ly / 8) * bpr + (lx / 8);
+                    if (m & (1u << bit)) continue;
+                    float dx = gxy0 - (float)gx, dy = gxy1 - (float)gy;
+                    float t1 = cx * dx * dx, t2 = cz * dy * dy, t3 = cy * dx * dy;
+                    float power = -0.5f * (t1 + t2) - t3;
+                    float alpha = wminf(0.99f, op * gso_expf(power));
+                    if (power <= 0.0f && alpha >= c255) m |= 1u << bit;
+                }
+        }
+        masks[i] = m;
+    }
+}
+
 GSO_API int gso_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

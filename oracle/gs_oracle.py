@@ -50,6 +50,8 @@ def lib():
         L.gso_blend.restype = None
         L.gso_blend.argtypes = [_u32p, _u32p, _u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                 ctypes.c_uint32, _u8p, _f32p, _u8p, _u32p]
+        L.gso_instance_masks.restype = None
+        L.gso_instance_masks.argtypes = [_u32p, _u32p, _u32p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _u32p]
         L.gso_num_threads.restype = ctypes.c_int
         L.gso_set_num_threads.argtypes = [ctypes.c_int]
         _lib = L
@@ -134,6 +136,17 @@ def blend(gdata, sorted_values, rng, W, H, ts=16, cols=None, want_f32=True, want
     lib().gso_blend(_p(gdata, _u32p), _p(sorted_values, _u32p), _p(rng, _u32p), W, H, ts, c0, c1, _p(rgba8, _u8p),
                     _p(rgbf, _f32p), _p(ill, _u8p), _p(proc, _u32p))
     return {"rgba8": rgba8, "rgbf": rgbf, "illcond": ill, "processed": proc}
+
+
+def instance_masks(gdata, keys, values, W, H, ts=16):
+    """Checker for the product path's tight binning: per instance of a (key, value) list, one bit per 8x8 pixel block of
+    its tile that holds a pixel passing `power <= 0 && alpha >= 1/255` (compute_tiles.wgsl:57-63).  mask 0 = the instance
+    cannot change any pixel."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    masks = np.zeros(keys.size, dtype=np.uint32)
+    lib().gso_instance_masks(_p(gdata, _u32p), _p(keys, _u32p), _p(values, _u32p), keys.size, W, H, ts, _p(masks, _u32p))
+    return masks
 
 
 def render(splats, uniforms, W, H, ts=16, cols=None, **blend_kw):

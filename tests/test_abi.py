@@ -25,14 +25,24 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libgsplat_hip.so does not export %s" % n
     assert sorted(_abi.ABI_SYMBOLS) == names
-    assert L.gs_abi_version() == 1
+    assert L.gs_abi_version() == 2
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors against what a C compiler makes of the header (sizeof / offsetof of every field)."""
+    import subprocess
     from gsplat import _abi
     assert ctypes.sizeof(_abi.GsConfig) == 48
     assert _abi.GsConfig.max_intersections.offset == 32 and _abi.GsConfig.stream.offset == 40
-    assert _abi.GsStats.stage_us.offset == 48 and ctypes.sizeof(_abi.GsStats) == 120
+    fields = [n for n, _ in _abi.GsStats._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "gsplat/gs_abi.h"\nint main(void){printf("%zu %zu", sizeof(gs_config), sizeof(gs_stats));'
+    prog += "".join('printf(" %%zu", offsetof(gs_stats, %s));' % n for n in fields) + "return 0;}\n"
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text(prog)
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_abi.GsConfig) and out[1] == ctypes.sizeof(_abi.GsStats)
+    assert out[2:] == [getattr(_abi.GsStats, n).offset for n in fields]
 
 
 def test_header_documents_reference_interfaces():

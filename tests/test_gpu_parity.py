@@ -12,56 +12,7 @@ from conftest import scene
 pytestmark = pytest.mark.gpu
 
 
-def _mk(splats, W, H, ts=16, flags=0, cols=None, **kw):
-    import gsplat
-    from gsplat import _abi
-    r = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, gsplat.PackedGaussians(splats), ts,
-                        flags=flags | _abi.GS_FLAG_F32_TAP, cols=cols, **kw)
-    return r
-
-
-def _uniforms(W, H, step=3):
-    from gsplat import synth
-    return synth.orbit_camera(step, W, H).uniforms(W, H)
-
-
-def _check_stages(r, ref, exact_image, debug=True):
-    """debug=True: the frame came from gs_render_debug (the reference's gaussian-index emission order, every tap valid);
-    debug=False: from gs_render (depth-ordered emission; the unsorted / offsets taps do not exist)."""
-    from gsplat import _abi
-    st = r.stats()
-    assert st["num_intersections"] == ref["num_intersections"]
-    assert st["num_visible"] == int((ref["tile_counts"] > 0).sum())
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_COUNTS), ref["tile_counts"])
-    if debug:
-        np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_OFFSETS), ref["offsets"])
-        gd = r.read_buffer(_abi.GS_BUF_GAUSSIAN_DATA).reshape(-1, 16)
-        np.testing.assert_array_equal(gd, ref["gdata"])  # floats compared as bits
-        np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS_UNSORTED), ref["keys"])
-        np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES_UNSORTED), ref["values"])
-    else:
-        gd = r.read_buffer(_abi.GS_BUF_GAUSSIAN_DATA).reshape(-1, 16)
-        vis = ref["tile_counts"] > 0  # records of culled gaussians are stale outside gs_render_debug
-        np.testing.assert_array_equal(gd[vis], ref["gdata"][vis])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ref["sorted_keys"])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), ref["sorted_values"])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RANGES), ref["ranges"])
-    img = r.read_rgba8()
-    f32 = r.read_buffer(_abi.GS_BUF_RGB_F32, np.float32).reshape(img.shape[0], img.shape[1], 3)
-    x0, w = r.slab_x0, r.slab_width
-    ref8 = ref["rgba8"][:, x0:x0 + w]
-    reff = ref["rgbf"][:, x0:x0 + w]
-    if exact_image:
-        np.testing.assert_array_equal(f32.view(np.uint32), reff.view(np.uint32))
-        np.testing.assert_array_equal(img, ref8)
-    else:
-        ill = ref["illcond"][:, x0:x0 + w].astype(bool)
-        err = np.abs(f32 - reff).max(axis=2)
-        assert err[~ill].max(initial=0.0) <= 1e-4, "fused blend deviates by %g" % err[~ill].max()
-        assert ill.mean() <= 0.005, "too many ill-conditioned pixels: %g" % ill.mean()
-        assert err.max(initial=0.0) <= 0.05
-        d8 = np.abs(img.astype(np.int32) - ref8.astype(np.int32))
-        assert d8[~ill].max(initial=0) <= 1
+from gpu_checks import check_product_lists, check_stages as _check_stages, make_renderer as _mk, orbit_uniforms as _uniforms
 
 
 @pytest.mark.parametrize("n,W,H,ts", [(10240, 256, 256, 16), (10000, 256, 256, 16), (3001, 200, 120, 16),
@@ -182,8 +133,7 @@ def test_determinism_and_reuse(oracle):
     u2 = _uniforms(W, H, step=40)
     ref = oracle.render(s, u2, W, H, 16)
     r.render_uniforms(u2); r.wait()
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ref["sorted_keys"])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), ref["sorted_values"])
+    check_product_lists(r, ref, oracle, W, H, 16)
     r.destroy()
 
 
@@ -238,10 +188,13 @@ def test_non_finite_splats(oracle):
         r = _mk(s, W, H, 16, flags=flags)
         for debug in (True, False):
             r.render_uniforms(u, debug=debug); r.wait()
-            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_COUNTS), ref["tile_counts"])
-            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ref["sorted_keys"])
-            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), ref["sorted_values"])
-            np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RANGES), ref["ranges"])
+            if debug:
+                np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_COUNTS), ref["tile_counts"])
+                np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ref["sorted_keys"])
+                np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), ref["sorted_values"])
+                np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RANGES), ref["ranges"])
+            else:
+                check_product_lists(r, ref, oracle, W, H, 16)
             img = r.read_rgba8()
             if flags:
                 np.testing.assert_array_equal(img, ref["rgba8"])
@@ -290,7 +243,7 @@ def test_reupload_and_two_contexts_in_threads(oracle):
     _abi.check(r._L.gs_upload_splats(r._ctx, arr.ctypes.data, arr.shape[0]))  # smaller scene into the same context
     r.render_uniforms(u); r.wait()
     np.testing.assert_array_equal(r.read_rgba8(), ra["rgba8"])
-    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), ra["sorted_keys"])
+    check_product_lists(r, ra, oracle, W, H, 16)
     arr = np.ascontiguousarray(sb, dtype=np.float32)
     _abi.check(r._L.gs_upload_splats(r._ctx, arr.ctypes.data, arr.shape[0]))  # and a larger one again
     r.render_uniforms(u); r.wait()

@@ -1,0 +1,272 @@
+"""BASELINE.json's configurations at FULL size on the GPU, against the CPU oracle (cfg-B..E).
+
+cfg-B  6.1 M splats @ 1920x1080: one whole frame vs oracle.render -- every tap of the gs_render_debug frame bit-equal, the
+       product frame's lists a provably harmless ordered subset, EXACT image bit-equal, fused image within 1e-4 off the
+       oracle's flagged pixels (fraction and errors printed and asserted).  Also observed: the first-frame capacity regrow,
+       the automatic switch to depth-ordered emission.
+cfg-C  same scene @ 3840x2160: integer stages vs oracle bit-equal; oracle image on a band of 16 tile columns (EXACT bits).
+cfg-D  the 8 tile-column slabs of cfg-C (30 columns each) rendered by 8 contexts on this GPU: union == whole frame, bytes.
+cfg-E  50 M splats @ 1920x1080: structural properties of the sorted lists + equality of the two emission orders.
+plus   a canvas whose tile ids do not fit 16 bits (the `by_tile` radix path of the depth-ordered pipeline).
+
+The scenes are generated on the GPU (synth.bicycle_like_torch, the generator bench.py uses) and copied to the host for the
+oracle, so both sides see identical bits.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from gpu_checks import check_image, check_product_lists, check_stages, make_renderer, orbit_uniforms
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _device_scene(n, seed_off):
+    import torch
+    from gsplat import synth
+    key = (n, seed_off)
+    if key not in _CACHE:
+        _CACHE.clear()  # one big scene at a time
+        dev = synth.bicycle_like_torch(n, synth.BASE_SEED + seed_off, "cuda")
+        torch.cuda.synchronize()
+        _CACHE[key] = dev
+    return _CACHE[key]
+
+
+def _pg(dev):
+    import gsplat
+    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+    pg.numGaussians, pg.gaussiansBuffer, pg.sphericalHarmonicsDegree = int(dev.shape[0]), dev, 3
+    return pg
+
+
+def _borrower(owner, W, H, ts, flags=0, cols=None):
+    import gsplat
+    from gsplat import _abi
+    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+    pg.numGaussians, pg.gaussiansBuffer = owner.numGaussians, None
+    return gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts, flags=flags | _abi.GS_FLAG_F32_TAP, cols=cols, share_with=owner)
+
+
+def test_config_B_full_frame(oracle):
+    from gsplat import _abi
+    n, W, H, ts = 6_100_000, 1920, 1080, 16
+    dev = _device_scene(n, 1)
+    host = dev.cpu().numpy()
+    u = orbit_uniforms(W, H, step=0)
+    t0 = time.time()
+    ref = oracle.render(host, u, W, H, ts, want_illcond=True)
+    t_oracle = time.time() - t0
+    r = make_renderer(_pg(dev), W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    cap0 = r.stats()["capacity"]
+    assert cap0 < ref["num_intersections"], "the default capacity is expected to be outgrown by this frame"
+    r.render_uniforms(u, debug=True)
+    r.wait()
+    st = r.stats()
+    assert st["capacity"] >= ref["num_intersections"] > cap0  # the first frame overflowed, was regrown and re-rendered
+    check_stages(r, ref, exact_image=True)
+    rep = {}
+    r.render_uniforms(u)  # product path; auto emission order now has an instance count to decide on
+    r.wait()
+    st = r.stats()
+    assert st["depth_ordered"] == 1, "a 42 M-instance frame must pick the depth-ordered pipeline"
+    check_stages(r, ref, exact_image=True, debug=False, oracle=oracle, W=W, H=H, ts=ts, report=rep)
+    r.set_option(_abi.GS_OPT_EMIT_ORDER, 1)  # the reference's emission order on the same frame
+    r.render_uniforms(u)
+    r.wait()
+    assert r.stats()["depth_ordered"] == 0
+    check_image(r, ref, exact_image=True)
+    keys1, vals1 = r.read_buffer(_abi.GS_BUF_KEYS), r.read_buffer(_abi.GS_BUF_VALUES)
+    r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)
+    r.render_uniforms(u)
+    r.wait()
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), keys1)
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), vals1)
+    # the benchmarked (fused) mode on the same frame
+    f = _borrower(r, W, H, ts)
+    f.render_uniforms(u)
+    f.wait()
+    check_image(f, ref, exact_image=False, max_ill=0.02, report=rep)
+    f.destroy()
+    r.destroy()
+    rep.update(oracle_seconds=round(t_oracle, 1), reference_intersections=int(ref["num_intersections"]))
+    print("\ncfg-B:", rep)
+    assert rep["flagged_fraction"] <= 0.02 and rep["max_err_unflagged"] <= 1e-4
+
+
+def test_config_C_4k_integer_stages_and_band(oracle):
+    from gsplat import _abi
+    n, W, H, ts = 6_100_000, 3840, 2160, 16
+    dev = _device_scene(n, 1)
+    host = dev.cpu().numpy()
+    u = orbit_uniforms(W, H, step=5)
+    ntx, nty = oracle.num_tiles(W, H, ts)
+    gd, counts = oracle.preprocess(host, u, W, H, ts)
+    offsets, total = oracle.scan(counts)
+    keys, values = oracle.emit(gd, offsets, counts, total, W, ts)
+    skeys, svalues = oracle.sort(keys, values)
+    rng = oracle.ranges(skeys, ntx * nty)
+    r = make_renderer(_pg(dev), W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.render_uniforms(u, debug=True)
+    r.wait()
+    assert r.stats()["num_intersections"] == total
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_COUNTS), counts)
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_TILE_OFFSETS), offsets)
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS_UNSORTED), keys)
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_KEYS), skeys)
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_VALUES), svalues)
+    np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RANGES), rng)
+    del keys, values, offsets
+    # oracle image on a band of tile columns (the whole 4K frame would take the CPU minutes)
+    c0, c1 = 112, 128
+    band = oracle.blend(gd, svalues, rng, W, H, ts, cols=(c0, c1))
+    img_dbg = r.read_rgba8()
+    np.testing.assert_array_equal(img_dbg[:, c0 * ts:c1 * ts], band["rgba8"][:, c0 * ts:c1 * ts])
+    ref = dict(gdata=gd, tile_counts=counts, num_intersections=total, sorted_keys=skeys, sorted_values=svalues, ranges=rng)
+    r.render_uniforms(u)  # product path: depth-ordered, 4-digit tile ids do not apply here (ids fit 16 bits: 2 digits)
+    r.wait()
+    assert r.stats()["depth_ordered"] == 1
+    rep = {}
+    check_product_lists(r, ref, oracle, W, H, ts, rep)
+    img = r.read_rgba8()
+    np.testing.assert_array_equal(img, img_dbg)  # whole frame: product path == reference-binning path, byte for byte
+    f32 = r.read_buffer(_abi.GS_BUF_RGB_F32, np.float32).reshape(H, W, 3)
+    np.testing.assert_array_equal(f32[:, c0 * ts:c1 * ts].view(np.uint32), band["rgbf"][:, c0 * ts:c1 * ts].view(np.uint32))
+    r.destroy()
+    print("\ncfg-C:", rep, "reference intersections", total)
+
+
+def test_config_D_eight_slabs_union(oracle):
+    """cfg-D's shape on one GPU: 8 contexts of 30 tile columns each at 3840x2160; their union is the whole frame."""
+    from gsplat import _abi, multigpu
+    n, W, H, ts = 6_100_000, 3840, 2160, 16
+    dev = _device_scene(n, 1)
+    u = orbit_uniforms(W, H, step=5)
+    owner = make_renderer(_pg(dev), W, H, ts)
+    owner.render_uniforms(u)
+    owner.wait()
+    whole = owner.read_rgba8()
+    bounds = multigpu.slab_bounds(W, ts, 8)
+    assert [b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:])] == [30] * 8
+    parts, inst = [], 0
+    for g in range(8):
+        s = _borrower(owner, W, H, ts, cols=(bounds[g], bounds[g + 1]))
+        for order in (2, 0):  # automatic order, then depth order forced
+            s.set_option(_abi.GS_OPT_EMIT_ORDER, order)
+            s.render_uniforms(u)
+            s.wait()
+            img = s.read_rgba8()
+            if order == 2:
+                parts.append(img)
+                inst += s.stats()["num_intersections"]
+            else:
+                np.testing.assert_array_equal(img, parts[-1])
+        s.destroy()
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), whole)
+    assert inst == owner.stats()["num_intersections"]  # every instance belongs to exactly one slab (aliased ones to column 0's)
+    owner.destroy()
+
+
+def test_config_E_50M_properties():
+    """50 M splats @ 1080p: the oracle would need minutes and 60 GB, so the size-independent properties of the lists are
+    checked instead: sum of counts = I, keys sorted, values ascending inside a key, ranges monotone and
+    consistent with the keys, both emission orders give identical lists and images."""
+    import torch
+    from gsplat import _abi
+    n, W, H, ts = 50_000_000, 1920, 1080, 16
+    dev = _device_scene(n, 4)
+    r = make_renderer(_pg(dev), W, H, ts)
+    _CACHE.clear()
+    del dev
+    torch.cuda.empty_cache()
+    u = orbit_uniforms(W, H, step=9)
+    r.set_option(_abi.GS_OPT_TILE_CULL, 0)  # the reference's binning: I ~ 350 M
+    out = {}
+    for order in (1, 0):
+        r.set_option(_abi.GS_OPT_EMIT_ORDER, order)
+        r.render_uniforms(u)
+        r.wait()
+        st = r.stats()
+        assert st["depth_ordered"] == (0 if order else 1)
+        I = st["num_intersections"]
+        keys, vals = r.read_buffer(_abi.GS_BUF_KEYS), r.read_buffer(_abi.GS_BUF_VALUES)
+        assert keys.size == vals.size == I
+        if order == 1:
+            counts = r.read_buffer(_abi.GS_BUF_TILE_COUNTS)
+            assert int(counts.sum(dtype=np.uint64)) == I and I > 200_000_000
+            assert (keys[1:] >= keys[:-1]).all()
+            same = keys[1:] == keys[:-1]
+            assert (vals[1:][same] >= vals[:-1][same]).all()  # stable: gaussian index order inside a key
+            assert vals.max() < n
+            np.testing.assert_array_equal(np.bincount(vals, minlength=n).astype(np.uint32), counts)
+            rng = r.read_buffer(_abi.GS_BUF_RANGES)
+            T = rng.size
+            assert (np.diff(rng.astype(np.int64)) >= 0).all() and rng[-1] <= I
+            np.testing.assert_array_equal(rng, np.searchsorted(keys // np.uint32(1000), np.arange(T, dtype=np.uint32), "right").astype(np.uint32))
+            out["keys"], out["vals"], out["img"] = keys, vals, r.read_rgba8()
+        else:
+            np.testing.assert_array_equal(keys, out["keys"])
+            np.testing.assert_array_equal(vals, out["vals"])
+            np.testing.assert_array_equal(r.read_rgba8(), out["img"])
+    del keys, vals
+    r.set_option(_abi.GS_OPT_TILE_CULL, 1)  # product path: same image from the tight lists
+    r.set_option(_abi.GS_OPT_EMIT_ORDER, 2)
+    r.render_uniforms(u)
+    r.wait()
+    st = r.stats()
+    np.testing.assert_array_equal(r.read_rgba8(), out["img"])
+    print("\ncfg-E: reference instances", out["keys"].size, "product instances", st["num_intersections"], "tight", st["tight_binning"])
+    r.destroy()
+
+
+def test_tile_ids_wider_than_16_bits(oracle):
+    """2048x2048 at tile 8: 65 792 tile ids -> the depth-ordered instance sort cannot use 16-bit sort words and orders u32
+    keys by key/1000 (`by_tile`), three radix digits."""
+    from conftest import scene
+    from gsplat import _abi
+    n, W, H, ts = 20000, 2048, 2048, 8
+    s, u = scene(n), orbit_uniforms(W, H, step=17)
+    ref = oracle.render(s, u, W, H, ts)
+    r = make_renderer(s, W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.render_uniforms(u, debug=True)
+    r.wait()
+    check_stages(r, ref, exact_image=True)
+    for cull in (0, 1):
+        r.set_option(_abi.GS_OPT_TILE_CULL, cull)
+        r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)
+        r.render_uniforms(u)
+        r.wait()
+        assert r.stats()["depth_ordered"] == 1
+        check_stages(r, ref, exact_image=True, debug=False, oracle=oracle, W=W, H=H, ts=ts)
+    r.destroy()
+
+
+def test_truncated_frames_are_reported(oracle):
+    """Several frames per gs_wait: when an EARLIER frame overflows the capacity, gs_wait must say so (GS_ERR_TRUNCATED), grow
+    the capacity, and the next round must be clean."""
+    from conftest import scene
+    from gsplat import _abi
+    n, W, H = 30000, 320, 192
+    s = scene(n)
+    us = [orbit_uniforms(W, H, step=k) for k in (3, 19, 40)]
+    need = max(oracle.render(s, u, W, H, 16)["num_intersections"] for u in us)
+    r = make_renderer(s, W, H, 16, max_intersections=4096, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.set_option(_abi.GS_OPT_TILE_CULL, 0)
+    assert need > 4096
+    for u in us:
+        r.render_uniforms(u)
+    with pytest.raises(_abi.GsError) as e:
+        r.wait()
+    assert e.value.code == -9 and "truncated" in str(e.value)
+    st = r.stats()
+    assert st["capacity"] >= need and st["truncated_frames"] == 2
+    ref = oracle.render(s, us[-1], W, H, 16)
+    np.testing.assert_array_equal(r.read_rgba8(), ref["rgba8"])  # the last frame was re-rendered and is complete
+    for u in us:
+        r.render_uniforms(u)
+    r.wait()  # no error this time
+    np.testing.assert_array_equal(r.read_rgba8(), ref["rgba8"])
+    r.destroy()
