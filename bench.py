@@ -358,9 +358,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # capacity calibration, outside warm-up and timing: every camera of the orbit once, waited for one by one, so that the
+    # (key,value) arrays have grown to the largest frame of the orbit before frames are enqueued back to back (a frame that
+    # overflows while others are queued behind it cannot be re-rendered: gs_wait reports GS_ERR_TRUNCATED)
+    for k in range(64):
+        r.render_uniforms(uniforms[k])
+        r.wait()
     for k in range(args.warmup):
         step(k)
     sync()
+    trouble.clear()
     r.set_option(_abi.GS_OPT_RESET_TIMING, 0)
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """On a GPU box torch's HIP runtime has to come up BEFORE libgsplat_hip.so's first HIP call in this process (the other
+    order leaves torch with "no ROCm-capable device"); the full-size tests generate their scenes with torch on the device."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import gs_oracle
