@@ -3,7 +3,7 @@
 #include "gs_device.h"
 
 void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream_t st);
-void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
+void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, bool tight,
                           hipStream_t st);
 uint32_t gs_project_emit_blocks(uint32_t n);
 void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, uint32_t* keys,
@@ -17,11 +17,16 @@ uint64_t gs_emit_chunks(uint64_t capacity);
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                              const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
                              uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st);
+// tight binning (gs_tight.h): counts are the projection's tight tile counts; by_index: elements are all N gaussians in index order
+void gs_launch_emit_tight(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
+                          const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
+                          uint32_t hist_bits, uint32_t hist_passes, bool keys16, bool by_index, hipStream_t st);
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
                         uint32_t* sticky, hipStream_t st);
-void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t* keys, hipStream_t st);
+void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t id_mask,
+                            uint32_t* keys, hipStream_t st);
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
                       uint32_t* sticky, hipStream_t st);
 uint32_t gs_sort_tiles(uint64_t capacity);
@@ -30,7 +35,7 @@ void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t*
                     uint32_t grid, bool have_hist, const uint32_t* aux_table, uint32_t* aux_out, hipStream_t st, uint32_t** out_keys,
                     uint32_t** out_vals, bool keys16 = false);
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, hipStream_t st);
+                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, bool masked, hipStream_t st);
 void gs_launch_debug_view(const uint32_t* ranges, const GsFrame& f, uint32_t view, uint32_t* rgba8, hipStream_t st);
 void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t height, const uint32_t* d_px_bounds, uint32_t n_slabs,
                         uint64_t slab_stride_px, hipStream_t st);

@@ -20,6 +20,7 @@
 
 #include "../../include/gsplat/gs_abi.h"
 #include "gs_kernels.h"
+#include "gs_tight.h"
 
 #define GS_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -247,7 +248,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
 
 GS_EXPORT int32_t gs_wait(gs_ctx* c);
 // Frees the previous scene and per-gaussian work arrays, allocates the work arrays for n gaussians.
-static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n) {
+static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity = 0) {
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
@@ -269,6 +270,7 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n) {
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
     uint64_t cap = c->cfg.max_intersections ? c->cfg.max_intersections : std::max<uint64_t>(4 * n, 1u << 22);
+    cap = std::max<uint64_t>(cap, min_capacity);
     cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
     return alloc_kv(c, cap);
 }
@@ -296,7 +298,9 @@ GS_EXPORT int32_t gs_share_splats(gs_ctx* c, gs_ctx* owner) {
     if (!owner->scene_mem) return fail(GS_ERR_NO_SCENE, "gs_share_splats: the owner holds no splats");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
-    int32_t rc = alloc_per_gaussian(c, owner->n);
+    // start from the capacity the owner has already grown to: a borrower exists to keep several frames in flight, and a
+    // frame that overflows while others are queued behind it cannot be re-rendered (GS_ERR_TRUNCATED)
+    int32_t rc = alloc_per_gaussian(c, owner->n, c->cfg.max_intersections ? 0 : owner->capacity);
     if (rc != GS_OK) return rc;
     c->scene_mem = owner->scene_mem; // read-only during a frame; the owner must outlive this context
     c->scene = owner->scene;
@@ -349,6 +353,8 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     } else {
         c->index_order = (c->emit_order == 1);
     }
+    // tight (opacity-aware) binning: product frames only; the sub-block mask shares the value word with the gaussian id
+    const bool tight = !debug && c->tile_cull && c->unfused && c->n < (1u << GS_ID_BITS);
     const bool fused = !debug && c->index_order && !c->unfused;
     if (fused) {
         // experimental (GS_OPT_UNFUSED 0): projection, scan and emission in ONE launch; measured 9 % slower than the three
@@ -357,7 +363,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         mark(c, 1);
         mark(c, 2);
     } else {
-        gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, st);
+        gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, tight, st);
         mark(c, 1);
     }
     const uint32_t scan_blocks = (uint32_t)(((size_t)gs_project_emit_blocks(c->n ? c->n : 1) + 1 + 31) & ~(size_t)31);
@@ -365,9 +371,14 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     if (fused) {
     } else if (by_index) {
         // the reference's order: scan counts in gaussian order, emit in gaussian order, sort by the full key
-        gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, tight ? c->chunk_table : nullptr,
+                       tight ? (uint32_t)gs_emit_chunks(c->capacity) : 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         mark(c, 2);
-        gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);
+        if (tight)
+            gs_launch_emit_tight(c->gdata, c->counts, c->offsets, nullptr, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, 8u, 0u,
+                                 false, /*by_index=*/true, st);
+        else
+            gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);
     } else {
         // Depth-ordered emission: the key is tile*1000 + bucket, and the required order inside a tile is (bucket,
         // gaussian index).  Sorting the N_vis visible GAUSSIANS by bucket first (stable, 10 bits, ~16x fewer elements
@@ -382,8 +393,12 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         gs_launch_scan(c->scounts, nullptr, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table,
                        (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
         mark(c, 2);
-        gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
-                                c->tile_bits, c->tile_passes, c->tile16, st);
+        if (tight)
+            gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
+                                 c->tile_bits, c->tile_passes, c->tile16, /*by_index=*/false, st);
+        else
+            gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
+                                    c->tile_bits, c->tile_passes, c->tile16, st);
     }
     const bool keys16 = !by_index && c->tile16;
     c->keysG_valid = false;
@@ -406,13 +421,14 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     c->last_passes = by_index ? c->passes : c->tile_passes;
     c->last_by_index = by_index;
     c->last_keys16 = keys16;
+    c->last_tight = tight;
     mark(c, 4);
     if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st);
     else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st); // streaming: 8 workgroups/CU
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
     const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, c->tile_depth, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
-                                        c->blend_ablation, st);
+                                        c->blend_ablation, tight, st);
     if (walkers < 0) return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
     c->blend_walkers = (uint32_t)walkers;
     mark(c, 6);
@@ -513,13 +529,14 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
         if (!c->keysG_valid) { // the frame was sorted on 16-bit tile ids: rebuild tile*1000 + bucket once
             if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
             if (!c->keysG) HIP_TRY(hipMalloc((void**)&c->keysG, (size_t)c->capacity * 4));
-            gs_launch_rebuild_keys((const uint16_t*)c->keysS, c->valsS, c->counts, (uint32_t)I, c->n, c->keysG, c->stream);
+            gs_launch_rebuild_keys((const uint16_t*)c->keysS, c->valsS, c->counts, (uint32_t)I, c->n, c->last_tight ? GS_ID_MASK : 0xFFFFFFFFu, c->keysG, c->stream);
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->keysG_valid = true;
         }
         *ptr = c->keysG;
         return GS_OK;
-    case GS_BUF_VALUES: *ptr = c->valsS; *bytes = I * 4; return GS_OK;
+    case GS_BUF_VALUES:
+    case GS_BUF_BLOCK_MASKS: *ptr = c->valsS; *bytes = I * 4; return GS_OK; // tight frames: id | mask << 28 (gs_read_buffer separates them)
     case GS_BUF_RANGES: *ptr = c->ranges; *bytes = (uint64_t)c->T * 4; return GS_OK;
     case GS_BUF_RGBA8: *ptr = c->last_ext ? c->last_ext : (void*)c->rgba8; *bytes = px * 4; return GS_OK;
     case GS_BUF_RGB_F32:
@@ -555,6 +572,25 @@ GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t s
     if (which == GS_BUF_TILE_COUNTS) { // device words also carry the depth bucket in their high 10 bits
         uint32_t* w = (uint32_t*)dst;
         for (uint64_t i = 0; i < bytes / 4; ++i) w[i] &= GS_COUNT_MASK;
+    }
+    if (which == GS_BUF_VALUES && c->last_tight) { // strip the sub-block mask
+        uint32_t* w = (uint32_t*)dst;
+        for (uint64_t i = 0; i < bytes / 4; ++i) w[i] &= GS_ID_MASK;
+    }
+    if (which == GS_BUF_BLOCK_MASKS) { // tight frame: the mask's sub-blocks (tile/2, or the whole 8-pixel tile) as 8x8-block bits
+        uint32_t* w = (uint32_t*)dst;
+        const uint32_t ts = c->frame.tile_size;
+        for (uint64_t i = 0; i < bytes / 4; ++i) {
+            const uint32_t m = w[i] >> GS_ID_BITS;
+            uint32_t out = m & (ts == 8 ? 1u : 0xFu);
+            if (ts == 32) { // quadrant q = (by/2)*2 + bx/2 of block (bx, by), 4 blocks per row
+                out = 0;
+                for (uint32_t by = 0; by < 4; ++by)
+                    for (uint32_t bx = 0; bx < 4; ++bx)
+                        if ((m >> ((by / 2) * 2 + bx / 2)) & 1u) out |= 1u << (by * 4 + bx);
+            }
+            w[i] = out;
+        }
     }
     return GS_OK;
 }

@@ -12,6 +12,7 @@
 // All three are HBM-bound integer kernels: scan 8 B/gaussian, emit 24 B/visible + 8 B/entry,
 // ranges 4 B/entry + 4 B/tile.
 #include "gs_device.h"
+#include "gs_tight.h"
 
 // ------------------------------------------------------------------------------------------------
 // Exclusive scan, 4096 counts per workgroup, status granule = {flag:2, visible:30, sum:32} in one 8-byte
@@ -406,6 +407,220 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tight emission (product path, gs_tight.h).  Same work split as gs_emit_balanced_kernel -- a wave owns EMIT_CHUNK
+// consecutive OUTPUT slots and walks the gaussians that cover them 64 at a time -- but a gaussian's instances are no
+// longer "every tile of its rect": they are, per tile row of the rect, the run of tiles that intersect its
+// alpha >= 1/255 ellipse (tight_row; the projection counted exactly these with the same function).  Two levels:
+//   row-items : lane = one (gaussian, tile row) of the group; computes the row's run and, by a wave scan segmented by
+//               gaussian, the output slot of its first instance;
+//   instances : lane = one output slot of the batch; finds its row-item by binary search in the batch's prefix (LDS),
+//               builds the sub-block mask from the two half-strip intervals of the row and stores (tile id, id | mask << 28).
+// The order of a gaussian's instances is free (a stable sort by tile follows and a gaussian meets a tile at most once,
+// the aliased duplicate excepted, which is identical); only the order of the gaussians matters, and that is `perm`'s.
+// perm == nullptr: gaussian-index order (the elements are all N gaussians, culled ones have count 0).
+// ------------------------------------------------------------------------------------------------
+struct EmitTightWave {
+    uint32_t off[64], rp[64], run[64], gid[64], y0b[64], cols[64];
+    float4 pA[64], pB[64], pC[64];
+    uint32_t incl[64], slot[64], rowbase[64], tlo[64], first[64], s0[64], s1[64];
+};
+
+__global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
+                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
+                                                             const uint32_t* __restrict__ chunk_table, GsFrame f,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ values, GsControl* ctl,
+                                                             uint32_t hist_bits, uint32_t hist_passes, uint32_t keys16, uint32_t by_index) {
+    __shared__ EmitTightWave s_w[4];
+    __shared__ uint32_t s_hist[4][256];
+    for (uint32_t k = threadIdx.x; k < 4 * 256; k += 256) (&s_hist[0][0])[k] = 0u;
+    __syncthreads();
+    const uint32_t hmask = (1u << hist_bits) - 1u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    EmitTightWave& S = s_w[w];
+    const uint32_t nel = by_index ? f.n : ctl->num_visible; // elements of the emission order
+    uint32_t total = ctl->num_intersections;
+    if (total > f.capacity) { // the frame does not fit: flag it, emit what fits (gs_wait grows and re-renders)
+        if (tid == 0 && blockIdx.x == 0) ctl->overflow = 1u;
+        total = f.capacity;
+    }
+    const uint32_t ts = f.tile_size, sub = ts >= 16u ? ts / 2u : ts, ns = ts / sub; // half strips per tile row: 1 (tile 8) or 2
+    const uint32_t full_mask = ns == 2u ? 0xFu : 0x1u;
+    const float Wf = (float)f.width, Hf = (float)f.height;
+    const uint32_t nchunks = (total + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT;
+    for (uint32_t c = blockIdx.x * 4u + w; c < nchunks; c += gridDim.x * 4u) {
+        const uint32_t S0 = c * EMIT_CHUNK;
+        const uint32_t S1 = (c + 1u) * EMIT_CHUNK < total ? (c + 1u) * EMIT_CHUNK : total;
+        uint32_t e = S0;
+        uint32_t kbase = chunk_table[c];
+        while (e < S1 && kbase < nel) {
+            // ---- the group: 64 consecutive elements of the emission order, one per lane ----
+            const uint32_t k = kbase + lane;
+            uint32_t off = 0xFFFFFFFFu, cnt = 0, nrows = 0, gid = 0, y0b = 0, colsw = 0;
+            TightG tg;
+            tg.gx = tg.gy = tg.cx = tg.cy = tg.cz = tg.cxz = tg.lim2 = tg.rcx = tg.xmax = tg.dyR = tg.eR = 0.0f;
+            tg.mode = 0u;
+            if (k < nel) {
+                const uint32_t packed = counts[k];
+                cnt = packed & GS_COUNT_MASK;
+                off = offsets[k];
+                if (cnt && off < S1) {
+                    gid = perm ? perm[k] : k;
+                    const uint4 r0 = gdata[(uint64_t)gid * 4 + 0], r1 = gdata[(uint64_t)gid * 4 + 1], r3 = gdata[(uint64_t)gid * 4 + 3];
+                    const float op = __uint_as_float(gdata[(uint64_t)gid * 4 + 2].w);
+                    tg = tight_setup(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y),
+                                     __uint_as_float(r1.z), op, Wf, Hf);
+                    uint32_t xa, wmain, alias;
+                    slab_cols_emit(r3.x, r3.z, f, xa, wmain, alias);
+                    const uint32_t y1 = r3.w < f.nty ? r3.w : f.nty;
+                    nrows = y1 > r3.y ? y1 - r3.y : 0u;
+                    y0b = r3.y | ((packed >> GS_COUNT_BITS) << 16);
+                    colsw = xa | (wmain << 16) | (alias << 31);
+                }
+            }
+            // slots covered by this group end where its last present member's instances end
+            uint32_t gend = (k < nel) ? off + cnt : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t o = __shfl_xor(gend, d, 64);
+                gend = o > gend ? o : gend;
+            }
+            const uint32_t stop = gend < S1 ? gend : S1;
+            const uint32_t rincl = wave_incl_scan(nrows, lane);
+            const uint32_t R = __shfl(rincl, 63, 64);
+            S.off[lane] = off;
+            S.rp[lane] = rincl - nrows;
+            S.run[lane] = 0u;
+            S.gid[lane] = gid;
+            S.y0b[lane] = y0b;
+            S.cols[lane] = colsw;
+            S.pA[lane] = make_float4(tg.gx, tg.gy, tg.cx, tg.cy);
+            S.pB[lane] = make_float4(tg.cz, tg.cxz, tg.lim2, tg.rcx);
+            S.pC[lane] = make_float4(tg.xmax, tg.dyR, tg.eR, __uint_as_float(tg.mode));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t rb = 0; rb < R; rb += 64) {
+                // ---- row-items: lane = (gaussian j of the group, tile row) ----
+                const uint32_t ri = rb + lane;
+                uint32_t len = 0, mainlen = 0, slot0 = 0, j = 0, rowbase = 0, tlo = 0, w0 = 0, w1 = 0;
+                if (ri < R) {
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) { // largest j with rp[j] <= ri (rows-less members share their successor's prefix)
+                        const uint32_t m = j + step;
+                        if (m < 64 && S.rp[m] <= ri) j = m;
+                    }
+                    const float4 a = S.pA[j], b = S.pB[j], cc = S.pC[j];
+                    TightG g;
+                    g.gx = a.x; g.gy = a.y; g.cx = a.z; g.cy = a.w; g.cz = b.x; g.cxz = b.y; g.lim2 = b.z; g.rcx = b.w;
+                    g.xmax = cc.x; g.dyR = cc.y; g.eR = cc.z; g.mode = __float_as_uint(cc.w);
+                    const uint32_t yb = S.y0b[j], cw = S.cols[j];
+                    const uint32_t ty = (yb & 0xFFFFu) + (ri - S.rp[j]);
+                    const uint32_t xa = cw & 0xFFFFu, wmain = (cw >> 16) & 0x7FFFu, alias = cw >> 31;
+                    TightRow r;
+                    len = tight_row(g, ty, ts, f.nty, xa, wmain, alias, r);
+                    mainlen = len - r.alias;
+                    rowbase = ty * f.ntx;
+                    tlo = (uint32_t)r.tlo;
+                    if (mainlen) {
+                        int lo[2], hi[2];
+                        const int cmin = (int)(tlo * ns), cmax = (int)((tlo + mainlen) * ns) - 1;
+                        tight_substrips(g, ty, ts, sub, cmin, cmax, lo, hi);
+                        w0 = (uint32_t)lo[0] | ((uint32_t)(hi[0] + 1) << 16);
+                        w1 = (uint32_t)lo[1] | ((uint32_t)(hi[1] + 1) << 16);
+                    }
+                }
+                // output slot of the row's first instance: the gaussian's offset + its rows before this batch + its rows before
+                // this one inside the batch (a wave scan, segmented by gaussian through the position of its first row-item)
+                const uint32_t lincl = wave_incl_scan(len, lane);
+                const uint32_t lexcl = lincl - len;
+                const uint32_t rp_j = (ri < R) ? S.rp[j] : 0u;
+                const uint32_t fl = rp_j > rb ? rp_j - rb : 0u; // lane of this gaussian's first row-item in the batch
+                const uint32_t excl_first = __shfl(lexcl, fl, 64);
+                if (ri < R) {
+                    const uint32_t within = lexcl - excl_first;
+                    const uint32_t carry = S.run[j];
+                    slot0 = S.off[j] + carry + within;
+                    // the gaussian's last row-item of the batch records what the batch added (one wave, in-order LDS: every
+                    // lane has read run[j] before this store is issued)
+                    const uint32_t rows_j = (j < 63u ? S.rp[j + 1] : R) - rp_j;
+                    const bool last_of_j = (ri + 1u == rp_j + rows_j) || lane == 63u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    if (last_of_j) S.run[j] = carry + within + len;
+                }
+                // clip to this wave's slots [S0, S1)
+                uint32_t j0 = 0, j1 = len;
+                if (slot0 < S0) j0 = S0 - slot0 < len ? S0 - slot0 : len;
+                if (slot0 + len > S1) j1 = S1 > slot0 ? S1 - slot0 : 0u;
+                const uint32_t lenx = j1 > j0 ? j1 - j0 : 0u;
+                const uint32_t xincl = wave_incl_scan(lenx, lane);
+                const uint32_t xtotal = __shfl(xincl, 63, 64);
+                S.incl[lane] = xincl;
+                S.slot[lane] = slot0 + j0;
+                S.rowbase[lane] = rowbase;
+                S.tlo[lane] = tlo;
+                S.first[lane] = j0 | (mainlen << 16);
+                S.s0[lane] = w0;
+                S.s1[lane] = w1;
+                const uint32_t owner_gid = (ri < R) ? S.gid[j] : 0u;
+                const uint32_t bucket = (ri < R) ? (S.y0b[j] >> 16) : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- instances: lane = one output slot of the batch ----
+                for (uint32_t t = lane; t < xtotal; t += 64) {
+                    uint32_t i = 0; // smallest i with incl[i] > t
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        const uint32_t m = i + step;
+                        if (m <= 64 && S.incl[m - 1] <= t) i = m;
+                    }
+                    const uint32_t ex = i ? S.incl[i - 1] : 0u;
+                    const uint32_t fw = S.first[i];
+                    const uint32_t q = (fw & 0xFFFFu) + (t - ex); // instance of the row
+                    const uint32_t ml = fw >> 16;
+                    const uint32_t dst = S.slot[i] + (t - ex);
+                    uint32_t tile_id, mask;
+                    if (q < ml) {
+                        const uint32_t tc = S.tlo[i] + q;
+                        tile_id = S.rowbase[i] + tc;
+                        const uint32_t a0 = S.s0[i], a1 = S.s1[i];
+                        if (ns == 2u) {
+                            const uint32_t c0 = 2u * tc, c1 = c0 + 1u;
+                            const uint32_t l0 = a0 & 0xFFFFu, h0 = a0 >> 16, l1 = a1 & 0xFFFFu, h1 = a1 >> 16;
+                            mask = (uint32_t)(l0 <= c0 && c0 < h0) | ((uint32_t)(l0 <= c1 && c1 < h0) << 1) |
+                                   ((uint32_t)(l1 <= c0 && c0 < h1) << 2) | ((uint32_t)(l1 <= c1 && c1 < h1) << 3);
+                        } else {
+                            mask = (uint32_t)((a0 & 0xFFFFu) <= tc && tc < (a0 >> 16));
+                        }
+                    } else { // the aliased instance: column ntx of this row = tile (row + 1, 0) (write_tile_ids.wgsl:29)
+                        tile_id = S.rowbase[i] + f.ntx;
+                        mask = full_mask;
+                    }
+                    const uint32_t og = __shfl(owner_gid, i, 64), ob = __shfl(bucket, i, 64);
+                    if (keys16) reinterpret_cast<uint16_t*>(keys)[dst] = (uint16_t)tile_id;
+                    else keys[dst] = tile_id * 1000u + ob;
+                    values[dst] = og | (mask << GS_ID_BITS);
+                    if (!by_index) { // digits of the tile id: the sort word of the depth-ordered pipeline (index order: the sort's own histogram pass)
+                        atomicAdd(&s_hist[0][tile_id & hmask], 1u);
+                        if (hist_passes > 1) atomicAdd(&s_hist[1][(tile_id >> hist_bits) & hmask], 1u);
+                        if (hist_passes > 2) atomicAdd(&s_hist[2][(tile_id >> (2 * hist_bits)) & hmask], 1u);
+                        if (hist_passes > 3) atomicAdd(&s_hist[3][(tile_id >> (3 * hist_bits)) & hmask], 1u);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            e = stop;
+            kbase += 64;
+        }
+    }
+    __syncthreads();
+    if (!by_index)
+        for (uint32_t p = 0; p < hist_passes; ++p) {
+            const uint32_t cnt = s_hist[p][threadIdx.x];
+            if (cnt) atomicAdd(&ctl->hist[p][threadIdx.x], cnt);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ranges: ranges[t] = |{ j < I : key_j/1000 <= t }| (entries with tile >= T ignored, A.6).
 // Boundary j in [0, I] owns the tiles t with tile[j-1] <= t < tile[j]  (tile[-1] = 0 bound, tile[I] = T):
 // every tile is written exactly once, so `ranges` never needs the reference's per-frame clear.
@@ -493,10 +708,10 @@ __global__ __launch_bounds__(256) void gs_ranges16_kernel(const uint16_t* __rest
 // GS_BUF_KEYS tap of a frame sorted on 16-bit tile ids: key = tile*1000 + depth bucket of the gaussian (the high bits of
 // its tile-count word), write_tile_ids.wgsl:31.
 __global__ __launch_bounds__(256) void gs_rebuild_keys_kernel(const uint16_t* __restrict__ tiles, const uint32_t* __restrict__ vals,
-                                                               const uint32_t* __restrict__ counts, uint32_t count, uint32_t n,
+                                                               const uint32_t* __restrict__ counts, uint32_t count, uint32_t n, uint32_t id_mask,
                                                                uint32_t* __restrict__ keys) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        const uint32_t g = vals[i];
+        const uint32_t g = vals[i] & id_mask;
         keys[i] = (uint32_t)tiles[i] * 1000u + (g < n ? counts[g] >> GS_COUNT_BITS : 0u);
     }
 }
@@ -506,11 +721,11 @@ void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t ca
                         uint32_t* sticky, hipStream_t st) {
     hipLaunchKernelGGL(gs_ranges16_kernel, dim3(grid), dim3(256), 0, st, tiles, ctl, capacity, T, ranges, sticky);
 }
-void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t* keys,
-                            hipStream_t st) {
+void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t id_mask,
+                            uint32_t* keys, hipStream_t st) {
     if (!count) return;
     const uint32_t blocks = (count + 255u) / 256u;
-    hipLaunchKernelGGL(gs_rebuild_keys_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, tiles, vals, counts, count, n, keys);
+    hipLaunchKernelGGL(gs_rebuild_keys_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, tiles, vals, counts, count, n, id_mask, keys);
 }
 uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
@@ -527,6 +742,12 @@ void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const ui
                              uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st) {
     hipLaunchKernelGGL(gs_emit_balanced_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, chunk_table, f, keys,
                        values, ctl, hist_bits, hist_passes, keys16 ? 1u : 0u);
+}
+void gs_launch_emit_tight(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
+                          const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
+                          uint32_t hist_bits, uint32_t hist_passes, bool keys16, bool by_index, hipStream_t st) {
+    hipLaunchKernelGGL(gs_emit_tight_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, chunk_table, f, keys,
+                       values, ctl, hist_bits, hist_passes, keys16 ? 1u : 0u, by_index ? 1u : 0u);
 }
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st) {

@@ -23,6 +23,7 @@
 // Bound: f32 VALU + transcendental issue (about 22 VALU slots per pixel x entry), not HBM:
 // algorithmic bytes are 40 B per staged entry + 4 B per pixel.
 #include "gs_device.h"
+#include "gs_tight.h"
 #include <type_traits>
 
 // Minimum over the pixel block [dxlo,dxhi] x [dylo,dyhi] (offsets g - p) of the quadratic
@@ -66,7 +67,7 @@ template <int TS, bool EXACT>
 __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                            const uint32_t* __restrict__ ranges, GsFrame f,
                                                            uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
-                                                           uint32_t dbg) {
+                                                           uint32_t dbg, uint32_t id_mask) {
     constexpr int NT = TS * TS;
     constexpr int ROUNDS = NT / 64; // 64-entry groups per batch
     constexpr int WPR = TS / 8;     // waves per tile row
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t rec = qrec + 16u * i; // entry (w*64 + rec) of the batch
-            uint32_t g = __shfl(gval, rec, 64);
+            uint32_t g = __shfl(gval, rec, 64) & id_mask; // tight frames: the sub-block mask rides in the high bits (gs_tight.h)
             if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION): gather from a cache-resident window
             if (b + w * 64u + rec < end && piece < 3u) rq[i] = gdata[(uint64_t)g * 4 + piece];
         }
@@ -255,7 +256,7 @@ template <bool EXACT>
 __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                             const uint32_t* __restrict__ ranges, GsFrame f,
                                                             uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
-                                                            uint32_t dbg) {
+                                                            uint32_t dbg, uint32_t id_mask) {
     constexpr int TS = 16;
     __shared__ float4 sP0[64]; // gx, gy, -, -
     __shared__ float4 sP1[64]; // conic (fused mode: pre-scaled), -
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restri
     auto fetch_id = [&](uint32_t b) { gnext = (b + lane < end) ? values[b + lane] : 0u; };
     auto fetch = [&](uint32_t b, uint32_t g) {
         if (b + lane < end) {
+            g &= id_mask;
             if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
             r0 = gdata[(uint64_t)g * 4 + 0];
             r1 = gdata[(uint64_t)g * 4 + 1];
@@ -412,7 +414,11 @@ __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restri
 // round-robin placement) so the three extra gathers of every record are normally L2 hits; placement
 // only affects speed.
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT, int TS = 16>
+// MASKED (tight frames, gs_tight.h): values[] holds gaussian id | sub-block mask << 28.  A walker looks at ITS bit before
+// it gathers: entries that cannot touch its pixels cost one id read and nothing else (no record gather, no cull
+// arithmetic).  At tile 16 the bit is per 8x8 block, i.e. exactly this walker's pixels, so the closed-form cull below is
+// skipped altogether; at tile 32 the bit is per 16x16 quadrant and the cull still runs on what the bit lets through.
+template <bool EXACT, int TS = 16, bool MASKED = false>
 __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                             const uint32_t* __restrict__ ranges, GsFrame f,
                                                             uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
@@ -455,10 +461,16 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     uint32_t staged = 0, evaluated = 0;
 
     uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
-    uint32_t gnext = 0;
+    uint32_t gnext = 0, vcur = 0; // value words of the next / the current batch's entry of this lane
+    // this walker's bit of the mask: its 8x8 block at tile 16, the 16x16 quadrant holding it at tile 32
+    constexpr bool QCULL = !MASKED || TS == 32;
+    const uint32_t mybit = GS_ID_BITS + (TS == 32 ? ((q / BPR) / 2u) * 2u + ((q % BPR) / 2u) : q);
     auto fetch_id = [&](uint32_t bb) { gnext = (bb + lane < end) ? values[bb + lane] : 0u; };
-    auto fetch = [&](uint32_t bb, uint32_t g) {
-        if (bb + lane < end) {
+    auto fetch = [&](uint32_t bb, uint32_t v) {
+        bool want = bb + lane < end;
+        if (MASKED) want = want && ((v >> mybit) & 1u);
+        if (want) {
+            uint32_t g = MASKED ? (v & GS_ID_MASK) : v;
             if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
             r0 = gdata[(uint64_t)g * 4 + 0];
             r1 = gdata[(uint64_t)g * 4 + 1];
@@ -467,23 +479,28 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     };
     if (start < end) {
         fetch_id(start);
-        fetch(start, gnext);
+        vcur = gnext;
+        fetch(start, vcur);
         fetch_id(start + 64);
     }
     for (uint32_t bb = start; bb < end; bb += 64) {
         const uint32_t cnt = (end - bb < 64u) ? end - bb : 64u;
         staged += cnt;
         bool rel = false, npd = false;
-        if (lane < cnt) {
+        if (lane < cnt && (!MASKED || ((vcur >> mybit) & 1u))) {
             const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
             const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
             const float op = __uint_as_float(r2.w);
             const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
             const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
-            const float dxhi = gxp - bx0f, dyhi = gyp - by0f;
-            float mag;
-            const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
-            rel = (!pd || !(qm > lim + 1.0e-5f * mag)) && !(dbg & 1u);
+            if (QCULL) {
+                const float dxhi = gxp - bx0f, dyhi = gyp - by0f;
+                float mag;
+                const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
+                rel = (!pd || !(qm > lim + 1.0e-5f * mag)) && !(dbg & 1u);
+            } else {
+                rel = !(dbg & 1u); // the emission already decided it for exactly these 64 pixels
+            }
             npd = rel && !pd;
             if (rel) { // only surviving entries are parked for the broadcast
                 const float L = 1.44269502162933349609375f;
@@ -503,8 +520,8 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         }
         const uint32_t nb = bb + 64;
         if (nb < end) {
-            const uint32_t g = gnext;
-            fetch(nb, g);
+            vcur = gnext;
+            fetch(nb, vcur);
             fetch_id(nb + 64);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -636,22 +653,32 @@ void gs_launch_debug_view(const uint32_t* ranges, const GsFrame& f, uint32_t vie
 // ---- host launchers --------------------------------------------------------------------------------
 template <int TS>
 static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* gdata, const uint32_t* values, const uint32_t* ranges,
-                           const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl, uint32_t dbg) {
+                           const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl, uint32_t dbg, uint32_t id_mask) {
     if (exact)
-        hipLaunchKernelGGL((gs_blend_kernel<TS, true>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg);
+        hipLaunchKernelGGL((gs_blend_kernel<TS, true>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
     else
-        hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg);
+        hipLaunchKernelGGL((gs_blend_kernel<TS, false>), grid, dim3(TS * TS), 0, st, gdata, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
+}
+template <int TS>
+static void launch_quad_t(bool exact, bool masked, uint32_t nblk, uint32_t pad, hipStream_t st, const uint4* g, const uint32_t* values,
+                          const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl, uint32_t* tile_depth,
+                          uint32_t dbg) {
+#define GS_QUAD(E, M) hipLaunchKernelGGL((gs_blend_quad_kernel<E, TS, M>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg)
+    if (exact) { if (masked) GS_QUAD(true, true); else GS_QUAD(true, false); }
+    else { if (masked) GS_QUAD(false, true); else GS_QUAD(false, false); }
+#undef GS_QUAD
 }
 // Returns -1 for an unsupported tile size, 4 when the quadrant kernel ran (gs_stats.num_processed is then the sum of
 // tile_depth[], the per-tile maximum over its four independent walkers), 1 otherwise (ctl->num_processed).
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, hipStream_t st) {
+                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, bool masked, hipStream_t st) {
     uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
+    const uint32_t id_mask = masked ? GS_ID_MASK : 0xFFFFFFFFu; // kernels without mask support only strip the bits
     const dim3 grid(f.col1 - f.col0, f.nty);
     if (grid.x == 0 || grid.y == 0) return 1;
     const uint4* g = (const uint4*)gdata;
     switch (f.tile_size) {
-    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1;
+    case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1;
     case 16:
     case 32: {
         // ablation bit 3 forces the 4-wave kernel, bit 4 the single-wave kernel; default: whole-tile waves once
@@ -686,19 +713,14 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
             // PROFILING ONLY: bits 6/7 reserve dynamic LDS so that only 2 / 4 waves fit a SIMD (occupancy sensitivity:
             // config B 8 waves -> 982 us, 4 -> 1214, 2 -> 1890)
             const uint32_t pad = (dbg & 64u) ? 20480u - 3072u : (dbg & 128u) ? 10240u - 3072u : 0u;
-            if (t32) {
-                if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true, 32>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
-                else hipLaunchKernelGGL((gs_blend_quad_kernel<false, 32>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
-                return 16;
-            }
-            if (exact) hipLaunchKernelGGL((gs_blend_quad_kernel<true>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
-            else hipLaunchKernelGGL((gs_blend_quad_kernel<false>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+            if (t32) { launch_quad_t<32>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg); return 16; }
+            launch_quad_t<16>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
             return 4;
         }
-        if (t32) { launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; } // ablation bit 3: 1024-thread workgroup per tile
-        if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg); return 1; }
-        if (exact) hipLaunchKernelGGL((gs_blend_wave_kernel<true>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
-        else hipLaunchKernelGGL((gs_blend_wave_kernel<false>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg);
+        if (t32) { launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1; } // ablation bit 3: 1024-thread workgroup per tile
+        if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1; }
+        if (exact) hipLaunchKernelGGL((gs_blend_wave_kernel<true>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
+        else hipLaunchKernelGGL((gs_blend_wave_kernel<false>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
         return 0;
     }
     default: return -1;

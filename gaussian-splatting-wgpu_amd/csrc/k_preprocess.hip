@@ -19,6 +19,7 @@
 // Algorithmic bytes per gaussian: 12 (culled) or 236 (visible) read; 4 (count) + 56 (visible) written.
 // Bound: HBM.  No MFMA (no contraction on this path).
 #include "gs_device.h"
+#include "gs_tight.h"
 
 // ---- upload: 320-byte AoS (ply.ts:190-198) -> position planes + 256-byte records ------------------
 // One thread per (gaussian, 16-byte column of the source record); runs once per scene.
@@ -80,6 +81,13 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
     alias = (rx1 == f.ntx + 1u && f.col0 == 0u) ? 1u : 0u;
 }
 
+// sigmoid (:282-294): both branches evaluated, blended by a 0/1 float
+__device__ __forceinline__ float sigmoid_ref(float o) {
+    const float ez = gs_exp(o);
+    const float cond = (o >= 0.0f) ? 1.0f : 0.0f;
+    return (cond * (1.0f / (1.0f + gs_exp(-o)))) + ((1.0f - cond) * (ez / (1.0f + ez)));
+}
+
 #define PRE_G 512 // gaussians per workgroup
 #ifndef PRE_WAVES
 #define PRE_WAVES 4 // waves per SIMD the register allocator must leave room for
@@ -96,7 +104,10 @@ __device__ __forceinline__ void slab_cols(uint32_t rx0, uint32_t rx1, const GsFr
 //                {flag, visible, sum} granule per workgroup (ticket-ordered, so it only waits on workgroups that have
 //                started) and expands its instances with coalesced stores straight from the rects it still holds in
 //                LDS.  Emission order is the reference's (gaussian index, y, x); offsets/rects never travel through HBM.
-template <bool FUSED>
+// TIGHT = true : the product path's opacity-aware binning (gs_tight.h): the tile count is the number of tiles of the rect that
+//                intersect the gaussian's alpha >= 1/255 ellipse (0 when its opacity is below 1/255), and the emission
+//                (gs_emit_tight_kernel) writes exactly those.  gs_render_debug and GS_OPT_TILE_CULL 0 use TIGHT = false.
+template <bool FUSED, bool TIGHT = false>
 __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
                                                              uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ keys,
                                                              uint32_t* __restrict__ values, unsigned long long* status,
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         const float det = ca * cc - cb * cb;
         uint32_t count = 0;
         uint32_t rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
-        float conx = 0.f, cony = 0.f, conz = 0.f;
+        float conx = 0.f, cony = 0.f, conz = 0.f, opacity = 0.f;
         if (det != 0.0f) { // :60 (det == 0 -> count 0, nothing written)
             const float det_inv = 1.0f / det;
             conx = cc * det_inv; cony = (-cb) * det_inv; conz = ca * det_inv;
@@ -243,6 +254,11 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             slab_cols(rminx, rmaxx, f, xa, wmain, alias);
             count = f.full ? (rmaxy - rminy) * (rmaxx - rminx) /* :86 */ : (rmaxy - rminy) * (wmain + alias);
             if (FUSED) s_erow[v] = xa | (wmain << 16) | (alias << 31);
+            if (TIGHT && count) {
+                opacity = sigmoid_ref(so.w);
+                const TightG tg = tight_setup(uvx, uvy, conx, cony, conz, opacity, (float)f.width, (float)f.height);
+                count = tight_count(tg, rminy, rmaxy, f.tile_size, f.nty, xa, wmain, alias);
+            }
         }
         // low 22 bits: tile count; high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
         const uint32_t bucket = f2u_sat(wg_min(50.0f * pv[2], 999.0f));
@@ -287,11 +303,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             res = res + 0.5f;
             col[c] = wg_max(res, 0.0f);
         }
-        // sigmoid: both branches evaluated, blended by a 0/1 float
-        const float o = so.w;
-        const float ez = gs_exp(o);
-        const float cond = (o >= 0.0f) ? 1.0f : 0.0f;
-        const float opacity = (cond * (1.0f / (1.0f + gs_exp(-o)))) + ((1.0f - cond) * (ez / (1.0f + ez)));
+        if (!TIGHT) opacity = sigmoid_ref(so.w);
         // GaussianData record (:97-104), 64 B as four 16-byte stores
         uint4* o4 = gdata + (uint64_t)i * 4;
         o4[0] = make_uint4(__float_as_uint(uvx), __float_as_uint(uvy), 0u, 0u);
@@ -394,12 +406,16 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
     hipLaunchKernelGGL(gs_repack_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)d_aos, n, (float*)s.px, (float*)s.py,
                        (float*)s.pz, (float*)s.smax, (float*)s.rec);
 }
-void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
+void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, bool tight,
                           hipStream_t st) {
     const uint32_t blocks = (f.n + PRE_G - 1) / PRE_G;
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_preprocess_kernel<false>, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr);
+    if (tight)
+        hipLaunchKernelGGL((gs_preprocess_kernel<false, true>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr);
+    else
+        hipLaunchKernelGGL((gs_preprocess_kernel<false, false>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr);
 }
 uint32_t gs_project_emit_blocks(uint32_t n) { return (n + PRE_G - 1) / PRE_G; }
 // projection + scan + emission in one launch; status: gs_project_emit_blocks(n) zeroed 8-byte words, ticket: one zeroed word
@@ -407,6 +423,6 @@ void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame
                             uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st) {
     const uint32_t blocks = gs_project_emit_blocks(f.n);
     if (!blocks) return;
-    hipLaunchKernelGGL(gs_preprocess_kernel<true>, dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, keys, values, status,
+    hipLaunchKernelGGL((gs_preprocess_kernel<true, false>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, keys, values, status,
                        ticket, ctl);
 }

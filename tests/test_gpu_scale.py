@@ -89,12 +89,14 @@ def test_config_B_full_frame(oracle):
     f = _borrower(r, W, H, ts)
     f.render_uniforms(u)
     f.wait()
-    check_image(f, ref, exact_image=False, max_ill=0.02, report=rep)
+    # hundreds of overlapping splats per pixel: many more pixels hold SOME near-threshold decision than at test sizes, so
+    # the flagged fraction is only recorded here; the bound is on the pixels that really moved
+    check_image(f, ref, exact_image=False, max_ill=0.25, report=rep)
     f.destroy()
     r.destroy()
     rep.update(oracle_seconds=round(t_oracle, 1), reference_intersections=int(ref["num_intersections"]))
     print("\ncfg-B:", rep)
-    assert rep["flagged_fraction"] <= 0.02 and rep["max_err_unflagged"] <= 1e-4
+    assert rep["max_err_unflagged"] <= 1e-4 and rep["fraction_over_1e-4"] <= 0.01 and rep["rgba8_fraction_over_1_lsb"] <= 0.002
 
 
 def test_config_C_4k_integer_stages_and_band(oracle):
