@@ -197,7 +197,7 @@ def self_check(gsplat, _abi, r, W, H, ts, device, u_last, args):
     d = np.abs(exact_img[..., :3].astype(np.int32) - fused_img[..., :3].astype(np.int32)).max(axis=2)
     detail = {"fused_vs_exact_pixels_off_by_more_than_1_lsb": int((d > 1).sum()), "fused_vs_exact_max_lsb": int(d.max()),
               "pixels": int(d.size), "tight_binning_frame_equals_reference_binning_frame": ref_binning_same}
-    ok = ref_binning_same and (d > 1).mean() <= 0.02
+    ok = bool(ref_binning_same and (d > 1).mean() <= 0.02)
     name = "fused_blend" if args.exact else "exact_blend"
     return {"frame_verified": ok, "frame_verified_detail": detail,
             name: {"value": other_fps, "unit": "frames/s", "steps": k, "note": "same scene and orbit, the other blend mode, short loop outside the timed region"}}
@@ -253,7 +253,10 @@ def main():
                          "splats, gs_share_splats) is reported as `pipelined`; 0 or 1 skips it.  `value` is always one frame in flight")
     ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
                     help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
+    ap.add_argument("--lib", default="", help="A/B only: another build of libgsplat_hip.so (sets $GSPLAT_LIB)")
     args = ap.parse_args()
+    if args.lib:
+        os.environ["GSPLAT_LIB"] = os.path.abspath(args.lib)
 
     import numpy as np
     import torch

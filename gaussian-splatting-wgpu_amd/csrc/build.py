@@ -28,7 +28,7 @@ def build(force=False, verbose=False):
     os.makedirs(OUT, exist_ok=True)
     objdir = os.path.join(OUT, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(HERE, h) for h in ("gs_device.h", "gs_kernels.h")] + [
+    headers = [os.path.join(HERE, h) for h in ("gs_device.h", "gs_kernels.h", "gs_tight.h")] + [
         os.path.join(HERE, "..", "..", "include", "gsplat", "gs_abi.h")]
 
     def compile_one(src):

@@ -35,7 +35,8 @@ void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t*
                     uint32_t grid, bool have_hist, const uint32_t* aux_table, uint32_t* aux_out, hipStream_t st, uint32_t** out_keys,
                     uint32_t** out_vals, bool keys16 = false);
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, bool masked, hipStream_t st);
+                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, bool masked, hipStream_t st, uint32_t* prof = nullptr,
+                    uint32_t* prof_blocks = nullptr);
 void gs_launch_debug_view(const uint32_t* ranges, const GsFrame& f, uint32_t view, uint32_t* rgba8, hipStream_t st);
 void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t height, const uint32_t* d_px_bounds, uint32_t n_slabs,
                         uint64_t slab_stride_px, hipStream_t st);

@@ -60,6 +60,8 @@ struct gs_ctx {
     bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
     uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
+    uint32_t* blend_prof = nullptr; // profiling only (ablation bit 16): 4 words per blend walker
+    uint32_t blend_prof_blocks = 0;
     // scene planes
     void* scene_mem = nullptr;
     GsScene scene{};
@@ -235,7 +237,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
-    hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky);
+    hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky); hipFree(c->blend_prof);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_sticky) hipHostFree(c->h_sticky);
     if (c->have_events)
@@ -427,8 +429,9 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st); // streaming: 8 workgroups/CU
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
+    if ((c->blend_ablation & 0x10000u) && !c->blend_prof) HIP_TRY(hipMalloc((void**)&c->blend_prof, (size_t)(1u << 20) * 16));
     const int walkers = gs_launch_blend(c->gdata, c->valsS, c->ranges, f, target, c->rgbf, c->ctl, c->tile_depth, (c->cfg.flags & GS_FLAG_EXACT_BLEND) != 0,
-                                        c->blend_ablation, tight, st);
+                                        c->blend_ablation & 0xFFFFu, tight, st, (c->blend_ablation & 0x10000u) ? c->blend_prof : nullptr, &c->blend_prof_blocks);
     if (walkers < 0) return fail(GS_ERR_INVALID_ARGUMENT, "unsupported tile size %u", f.tile_size);
     c->blend_walkers = (uint32_t)walkers;
     mark(c, 6);
@@ -539,6 +542,9 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
     case GS_BUF_BLOCK_MASKS: *ptr = c->valsS; *bytes = I * 4; return GS_OK; // tight frames: id | mask << 28 (gs_read_buffer separates them)
     case GS_BUF_RANGES: *ptr = c->ranges; *bytes = (uint64_t)c->T * 4; return GS_OK;
     case GS_BUF_RGBA8: *ptr = c->last_ext ? c->last_ext : (void*)c->rgba8; *bytes = px * 4; return GS_OK;
+    case 11: // PROFILING ONLY: per-walker stamps of the blend (GS_OPT_BLEND_ABLATION bit 16)
+        if (!c->blend_prof) return fail(GS_ERR_INVALID_ARGUMENT, "no blend profile (GS_OPT_BLEND_ABLATION bit 16)");
+        *ptr = c->blend_prof; *bytes = (uint64_t)c->blend_prof_blocks * 16; return GS_OK;
     case GS_BUF_RGB_F32:
         if (!c->rgbf) return fail(GS_ERR_INVALID_ARGUMENT, "GS_BUF_RGB_F32 needs GS_FLAG_F32_TAP");
         *ptr = c->rgbf; *bytes = px * 12; return GS_OK;

@@ -112,22 +112,32 @@ __device__ __forceinline__ void tight_cols(float plo, float phi, float w, int cm
 
 // The tiles of tile row ty that gaussian g is emitted to, for a rect whose slab-clipped columns are [xa, xa + wmain)
 // (slab_cols: real columns only) plus `alias` (the reference's column ntx, which lands in column 0 of the next row).
-// Returns the instance count of the row; tlo..thi = its real tile columns (tlo > thi: none).
+// Returns the instance count of the row; tlo..thi = its real tile columns (tlo > thi: none); r.alias = the aliased one is kept.
 struct TightRow { int tlo, thi; uint32_t alias; };
+// Tile columns [cmin, cmax] of tile row ty that intersect E (mode 1); empty: lo > hi.
+__device__ __forceinline__ void tight_row_cols(const TightG& g, uint32_t ty, uint32_t ts, int cmin, int cmax, int& lo, int& hi) {
+    lo = cmax + 1; hi = cmin - 1;
+    const float b = g.gy - (float)(ty * ts), a = g.gy - (float)((ty + 1u) * ts); // pixel rows [ty ts, (ty+1) ts], continuous
+    float lo_a, hi_a, lo_b, hi_b, plo, phi;
+    const bool va = tight_chord(g, a, lo_a, hi_a), vb = tight_chord(g, b, lo_b, hi_b);
+    if (tight_strip(g, a, b, va, lo_a, hi_a, vb, lo_b, hi_b, plo, phi)) tight_cols(plo, phi, (float)ts, cmin, cmax, lo, hi);
+}
 __device__ __forceinline__ uint32_t tight_row(const TightG& g, uint32_t ty, uint32_t ts, uint32_t nty, uint32_t xa, uint32_t wmain,
                                               uint32_t alias, TightRow& r) {
-    r.tlo = 0; r.thi = -1;
-    // the aliased instance of row ty belongs to tile (ty + 1, 0): kept whenever that tile exists (rare, never tested)
-    r.alias = (alias && ty + 1u < nty) ? 1u : 0u;
-    if (ty >= nty) { r.alias = 0u; return 0u; } // rows past the grid never reach the blend (compute_ranges ignores tiles >= T)
+    r.tlo = 0; r.thi = -1; r.alias = 0u;
+    if (ty >= nty) return 0u; // rows past the grid never reach the blend (compute_ranges ignores tiles >= T)
     if (wmain) {
         if (g.mode == 2u) { r.tlo = (int)xa; r.thi = (int)(xa + wmain) - 1; }
+        else tight_row_cols(g, ty, ts, (int)xa, (int)(xa + wmain) - 1, r.tlo, r.thi);
+    }
+    // the aliased instance of row ty (the reference's column ntx) IS tile (ty + 1, 0): kept if that tile exists and
+    // intersects E -- at the far side of the screen from the gaussian, so almost never
+    if (alias && ty + 1u < nty) {
+        if (g.mode == 2u) r.alias = 1u;
         else {
-            const float b = g.gy - (float)(ty * ts), a = g.gy - (float)((ty + 1u) * ts); // pixel rows [ty ts, (ty+1) ts], continuous
-            float lo_a, hi_a, lo_b, hi_b, plo, phi;
-            const bool va = tight_chord(g, a, lo_a, hi_a), vb = tight_chord(g, b, lo_b, hi_b);
-            if (tight_strip(g, a, b, va, lo_a, hi_a, vb, lo_b, hi_b, plo, phi))
-                tight_cols(plo, phi, (float)ts, (int)xa, (int)(xa + wmain) - 1, r.tlo, r.thi);
+            int lo, hi;
+            tight_row_cols(g, ty + 1u, ts, 0, 0, lo, hi);
+            r.alias = lo <= hi ? 1u : 0u;
         }
     }
     return (uint32_t)(r.thi >= r.tlo ? r.thi - r.tlo + 1 : 0) + r.alias;

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
 struct EmitTightWave {
     uint32_t off[64], rp[64], run[64], gid[64], y0b[64], cols[64];
     float4 pA[64], pB[64], pC[64];
-    uint32_t incl[64], slot[64], rowbase[64], tlo[64], first[64], s0[64], s1[64];
+    uint32_t incl[64], slot[64], rowbase[64], tlo[64], first[64], s0[64], s1[64], rgid[64], rbucket[64], amask[64];
 };
 
 __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
@@ -444,7 +444,6 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
         total = f.capacity;
     }
     const uint32_t ts = f.tile_size, sub = ts >= 16u ? ts / 2u : ts, ns = ts / sub; // half strips per tile row: 1 (tile 8) or 2
-    const uint32_t full_mask = ns == 2u ? 0xFu : 0x1u;
     const float Wf = (float)f.width, Hf = (float)f.height;
     const uint32_t nchunks = (total + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT;
     for (uint32_t c = blockIdx.x * 4u + w; c < nchunks; c += gridDim.x * 4u) {
@@ -501,7 +500,7 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
             for (uint32_t rb = 0; rb < R; rb += 64) {
                 // ---- row-items: lane = (gaussian j of the group, tile row) ----
                 const uint32_t ri = rb + lane;
-                uint32_t len = 0, mainlen = 0, slot0 = 0, j = 0, rowbase = 0, tlo = 0, w0 = 0, w1 = 0;
+                uint32_t len = 0, mainlen = 0, slot0 = 0, j = 0, rowbase = 0, tlo = 0, w0 = 0, w1 = 0, am = 0;
                 if (ri < R) {
 #pragma unroll
                     for (int step = 32; step >= 1; step >>= 1) { // largest j with rp[j] <= ri (rows-less members share their successor's prefix)
@@ -526,6 +525,12 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
                         tight_substrips(g, ty, ts, sub, cmin, cmax, lo, hi);
                         w0 = (uint32_t)lo[0] | ((uint32_t)(hi[0] + 1) << 16);
                         w1 = (uint32_t)lo[1] | ((uint32_t)(hi[1] + 1) << 16);
+                    }
+                    if (r.alias) { // its sub-blocks: tile (ty + 1, 0)
+                        int lo[2], hi[2];
+                        tight_substrips(g, ty + 1u, ts, sub, 0, (int)ns - 1, lo, hi);
+                        am = (uint32_t)(lo[0] <= 0 && 0 <= hi[0]);
+                        if (ns == 2u) am |= ((uint32_t)(lo[0] <= 1 && 1 <= hi[0]) << 1) | ((uint32_t)(lo[1] <= 0 && 0 <= hi[1]) << 2) | ((uint32_t)(lo[1] <= 1 && 1 <= hi[1]) << 3);
                     }
                 }
                 // output slot of the row's first instance: the gaussian's offset + its rows before this batch + its rows before
@@ -560,8 +565,9 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
                 S.first[lane] = j0 | (mainlen << 16);
                 S.s0[lane] = w0;
                 S.s1[lane] = w1;
-                const uint32_t owner_gid = (ri < R) ? S.gid[j] : 0u;
-                const uint32_t bucket = (ri < R) ? (S.y0b[j] >> 16) : 0u;
+                S.amask[lane] = am;
+                S.rgid[lane] = (ri < R) ? S.gid[j] : 0u; // (through LDS, not a shuffle: the instance loop's last trip is divergent)
+                S.rbucket[lane] = (ri < R) ? (S.y0b[j] >> 16) : 0u;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // ---- instances: lane = one output slot of the batch ----
@@ -592,9 +598,9 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
                         }
                     } else { // the aliased instance: column ntx of this row = tile (row + 1, 0) (write_tile_ids.wgsl:29)
                         tile_id = S.rowbase[i] + f.ntx;
-                        mask = full_mask;
+                        mask = S.amask[i];
                     }
-                    const uint32_t og = __shfl(owner_gid, i, 64), ob = __shfl(bucket, i, 64);
+                    const uint32_t og = S.rgid[i], ob = S.rbucket[i];
                     if (keys16) reinterpret_cast<uint16_t*>(keys)[dst] = (uint16_t)tile_id;
                     else keys[dst] = tile_id * 1000u + ob;
                     values[dst] = og | (mask << GS_ID_BITS);

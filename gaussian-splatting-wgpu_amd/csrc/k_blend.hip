@@ -418,12 +418,17 @@ __global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restri
 // it gathers: entries that cannot touch its pixels cost one id read and nothing else (no record gather, no cull
 // arithmetic).  At tile 16 the bit is per 8x8 block, i.e. exactly this walker's pixels, so the closed-form cull below is
 // skipped altogether; at tile 32 the bit is per 16x16 quadrant and the cull still runs on what the bit lets through.
+typedef uint32_t gs_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t gs_u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t gs_u32x4 __attribute__((ext_vector_type(4)));
 template <bool EXACT, int TS = 16, bool MASKED = false>
 __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
                                                             const uint32_t* __restrict__ ranges, GsFrame f,
                                                             uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
-                                                            uint32_t* __restrict__ tile_depth, uint32_t dbg) {
-    constexpr uint32_t BPR = TS / 8, NB = BPR * BPR; // 8x8 pixel blocks per tile row / per tile (4 at tile 16, 16 at tile 32)
+                                                            uint32_t* __restrict__ tile_depth, uint32_t dbg, uint32_t* __restrict__ prof) {
+    constexpr uint32_t BPR = TS / 8, NB = BPR * BPR;
+    // PROFILING ONLY (prof != nullptr, GS_OPT_BLEND_ABLATION bit 16): start / end stamp (100 MHz), evaluated and staged entries per walker
+    const uint32_t t_start = prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; // 8x8 pixel blocks per tile row / per tile (4 at tile 16, 16 at tile 32)
     __shared__ float4 sP0[64];
     __shared__ float4 sP1[64];
     __shared__ float4 sP2[64];
@@ -443,7 +448,12 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     const uint32_t lastw = slab_tx - (ns - 1) * SW;
     const uint32_t Wx = n_x * SW - ((((ns - 1) & 7u) == x) ? SW - lastw : 0u); // tile columns owned by XCD x
     if (t >= Wx * f.nty) return;
-    const uint32_t ty = t / Wx, cc = t % Wx;
+    uint32_t ty = t / Wx;
+    const uint32_t cc = t % Wx;
+    if (dbg & 32u) { // EXPERIMENT: tile rows from the middle of the screen outwards (heavy tiles first)
+        const uint32_t mid = f.nty / 2u;
+        ty = (ty & 1u) ? mid - (ty + 1u) / 2u : mid + ty / 2u;
+    }
     const uint32_t tx = f.col0 + (x + 8u * (cc / SW)) * SW + cc % SW;
     const uint32_t lin = ty * slab_tx + (tx - f.col0);
     const uint32_t tile = tx + ty * f.ntx;
@@ -460,22 +470,32 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     uint32_t staged = 0, evaluated = 0;
 
-    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    // the three pieces of a record a lane fetches (uv | conic | colour, opacity), as native vectors: each is ONE register tuple
+    // from the load to the asm pin below, so nothing has to be copied (and waited for) in between
+    gs_u32x2 r0 = {0u, 0u};
+    gs_u32x3 r1 = {0u, 0u, 0u};
+    gs_u32x4 r2 = {0u, 0u, 0u, 0u};
     uint32_t gnext = 0, vcur = 0; // value words of the next / the current batch's entry of this lane
     // this walker's bit of the mask: its 8x8 block at tile 16, the 16x16 quadrant holding it at tile 32
     constexpr bool QCULL = !MASKED || TS == 32;
     const uint32_t mybit = GS_ID_BITS + (TS == 32 ? ((q / BPR) / 2u) * 2u + ((q % BPR) / 2u) : q);
-    auto fetch_id = [&](uint32_t bb) { gnext = (bb + lane < end) ? values[bb + lane] : 0u; };
+    // Both loads are UNCONDITIONAL (a lane without work reads the list's last id / record 0, lines every wave shares): an
+    // exec-masked load leaves the compiler merging old and new registers right behind the load, i.e. waiting for it at
+    // once, and the prefetch below would be a prefetch in name only (it was, until round 2).
+    auto fetch_id = [&](uint32_t bb) {
+        const uint32_t i = bb + lane;
+        gnext = values[i < end ? i : end - 1u];
+    };
     auto fetch = [&](uint32_t bb, uint32_t v) {
         bool want = bb + lane < end;
         if (MASKED) want = want && ((v >> mybit) & 1u);
-        if (want) {
-            uint32_t g = MASKED ? (v & GS_ID_MASK) : v;
-            if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
-            r0 = gdata[(uint64_t)g * 4 + 0];
-            r1 = gdata[(uint64_t)g * 4 + 1];
-            r2 = gdata[(uint64_t)g * 4 + 2];
-        }
+        uint32_t g = MASKED ? (v & GS_ID_MASK) : v;
+        if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
+        g = want ? g : 0u;
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(gdata + (uint64_t)g * 4);
+        r0 = *reinterpret_cast<const gs_u32x2*>(rec);
+        r1 = *reinterpret_cast<const gs_u32x3*>(rec + 4);
+        r2 = *reinterpret_cast<const gs_u32x4*>(rec + 8);
     };
     if (start < end) {
         fetch_id(start);
@@ -487,6 +507,10 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         const uint32_t cnt = (end - bb < 64u) ? end - bb : 64u;
         staged += cnt;
         bool rel = false, npd = false;
+        // The records fetched one batch ago are first needed HERE.  The empty asm pins that: without it the compiler copies the
+        // loaded registers into the operand tuples of the LDS stores / packed multiplies right behind the loads, and the
+        // s_waitcnt that copy needs turns the prefetch into a blocking gather (seen in the ISA of every build before this one).
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2));
         if (lane < cnt && (!MASKED || ((vcur >> mybit) & 1u))) {
             const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
             const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
@@ -580,6 +604,12 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     // (tile_depth[] is zeroed with the control block; the host sums it)
     if (lane == 0 && staged) atomicMax(&tile_depth[lin], staged);
     if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(b + 1u) & 63u], (unsigned long long)evaluated);
+    if (prof && lane == 0) {
+        prof[b * 4u + 0u] = t_start;
+        prof[b * 4u + 1u] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        prof[b * 4u + 2u] = evaluated;
+        prof[b * 4u + 3u] = staged;
+    }
     if (!outside) {
         const float c[3] = {cr, cg, cb};
         uint32_t px = 0xFF000000u;
@@ -662,8 +692,8 @@ static void launch_blend_t(bool exact, dim3 grid, hipStream_t st, const uint4* g
 template <int TS>
 static void launch_quad_t(bool exact, bool masked, uint32_t nblk, uint32_t pad, hipStream_t st, const uint4* g, const uint32_t* values,
                           const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf, GsControl* ctl, uint32_t* tile_depth,
-                          uint32_t dbg) {
-#define GS_QUAD(E, M) hipLaunchKernelGGL((gs_blend_quad_kernel<E, TS, M>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg)
+                          uint32_t dbg, uint32_t* prof) {
+#define GS_QUAD(E, M) hipLaunchKernelGGL((gs_blend_quad_kernel<E, TS, M>), dim3(nblk), dim3(64), pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg, prof)
     if (exact) { if (masked) GS_QUAD(true, true); else GS_QUAD(true, false); }
     else { if (masked) GS_QUAD(false, true); else GS_QUAD(false, false); }
 #undef GS_QUAD
@@ -671,7 +701,8 @@ static void launch_quad_t(bool exact, bool masked, uint32_t nblk, uint32_t pad, 
 // Returns -1 for an unsupported tile size, 4 when the quadrant kernel ran (gs_stats.num_processed is then the sum of
 // tile_depth[], the per-tile maximum over its four independent walkers), 1 otherwise (ctl->num_processed).
 int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* ranges, const GsFrame& f, uint32_t* rgba8, float* rgbf,
-                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, bool masked, hipStream_t st) {
+                    GsControl* ctl, uint32_t* tile_depth, bool exact, uint32_t ablation, bool masked, hipStream_t st, uint32_t* prof,
+                    uint32_t* prof_blocks) {
     uint32_t dbg = ablation; // GS_OPT_BLEND_ABLATION: 0 = product path
     const uint32_t id_mask = masked ? GS_ID_MASK : 0xFFFFFFFFu; // kernels without mask support only strip the bits
     const dim3 grid(f.col1 - f.col0, f.nty);
@@ -713,8 +744,9 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
             // PROFILING ONLY: bits 6/7 reserve dynamic LDS so that only 2 / 4 waves fit a SIMD (occupancy sensitivity:
             // config B 8 waves -> 982 us, 4 -> 1214, 2 -> 1890)
             const uint32_t pad = (dbg & 64u) ? 20480u - 3072u : (dbg & 128u) ? 10240u - 3072u : 0u;
-            if (t32) { launch_quad_t<32>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg); return 16; }
-            launch_quad_t<16>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg);
+            if (prof_blocks) *prof_blocks = nblk;
+            if (t32) { launch_quad_t<32>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg, prof); return 16; }
+            launch_quad_t<16>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg, prof);
             return 4;
         }
         if (t32) { launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1; } // ablation bit 3: 1024-thread workgroup per tile

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "lib", "libgsplat_hip.so"))
+# $GSPLAT_LIB: another build of the same library (A/B measurements of compiler flags); never a different implementation
+LIB_PATH = os.environ.get("GSPLAT_LIB") or os.path.abspath(os.path.join(_HERE, "..", "lib", "libgsplat_hip.so"))
 
 GS_FLAG_EXACT_BLEND = 0x1
 GS_FLAG_F32_TAP = 0x2

@@ -100,7 +100,10 @@ def check_product_lists(r, ref, oracle, W, H, ts, report=None):
     assert st["num_visible"] == int((counts > 0).sum())
     gd = r.read_buffer(_abi.GS_BUF_GAUSSIAN_DATA).reshape(-1, 16)
     vis = counts > 0
-    np.testing.assert_array_equal(gd[vis], ref["gdata"][vis])
+    a, b = gd[vis], ref["gdata"][vis]
+    same = (a == b) | (np.isnan(a.view(np.float32)) & np.isnan(b.view(np.float32)))  # a NaN's sign/payload is not defined
+    same[:, 12:] = a[:, 12:] == b[:, 12:]  # the rect words are integers
+    assert same.all(), "GaussianData differs in %d words" % int((~same).sum())
     if report is not None:
         report.update(reference_instances=int(rc.size), product_instances=int(gc.size),
                       kept_fraction=float(gc.size) / max(int(rc.size), 1),

@@ -63,7 +63,13 @@ int main(int argc, char** argv) {
                             sets[g][ty * ntx + tc] |= 0x100 | m;
                         }
                     }
-                    if (r.alias) sets[g][ty * ntx + ntx] |= 0x100 | (ns == 2 ? 0xF : 1);
+                    if (r.alias) {
+                        int lo[2], hi2[2];
+                        tight_substrips(tg, ty + 1, ts, sub, 0, (int)ns - 1, lo, hi2);
+                        uint32_t am = (lo[0] <= 0 && 0 <= hi2[0]);
+                        if (ns == 2) am |= ((lo[0] <= 1 && 1 <= hi2[0]) << 1) | ((lo[1] <= 0 && 0 <= hi2[1]) << 2) | ((lo[1] <= 1 && 1 <= hi2[1]) << 3);
+                        sets[g][ty * ntx + ntx] |= 0x100 | am;
+                    }
                 }
             if (got != cnt) { printf("count mismatch g=%u %u vs %u\n", g, got, cnt); return 1; }
             total_tight += cnt;
