@@ -33,7 +33,7 @@ struct TightG {
     float cxz;         // cx * cz
     float lim2;        // 2 (ln(255 opacity) + margin): the pixel can pass only if cx dx^2 + 2 cy dx dy + cz dy^2 <= lim2
     float rcx;         // 1 / cx
-    float xmax;        // half extent of E in x, inflated
+    float xmax, ymax;  // half extents of E in x and y, inflated
     float dyR, eR;     // dy of E's rightmost point (the leftmost is at -dyR) and the uncertainty of that estimate
     uint32_t mode;     // 0: cannot pass anywhere (opacity < 1/255), 1: ellipse test, 2: keep the reference's whole rect
 };
@@ -53,16 +53,20 @@ __device__ __forceinline__ TightG tight_setup(float uvx, float uvy, float cx, fl
     const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // v_log_f32 (log2) * ln 2
     g.lim2 = 2.0f * lim;
     g.rcx = 1.0f / cx;
-    g.xmax = 0.0f; g.dyR = 0.0f; g.eR = 0.0f;
+    g.xmax = 0.0f; g.ymax = 0.0f; g.dyR = 0.0f; g.eR = 0.0f;
     const bool pd = (cx > 0.0f) && (cz > 0.0f) && (D > 0.0f);
     const bool fin = tight_finite(g.gx) && tight_finite(g.gy) && tight_finite(cx) && tight_finite(cy) && tight_finite(cz) && tight_finite(g.rcx);
     if (lim < 0.0f) { g.mode = 0u; return g; }                                  // (-inf included; NaN falls through to mode 2)
-    if (!pd || !fin || !tight_finite(lim) || !(D > 4.0f * errD)) { g.mode = 2u; return g; } // non-PD conic, NaN/inf, or cx cz - cy^2 lost to cancellation
-    const float Dlo = D - errD;
-    g.xmax = __builtin_sqrtf(g.lim2 * cz / Dlo) * 1.0002f + 0.02f;
+    // Dlo: a lower bound of cx cz - cy^2 that also covers the inflation of tight_chord's discriminant (1e-5 of its terms), so
+    // that xmax / ymax bound every chord tight_chord accepts: a row beyond ymax then yields nothing whether it is looked at or
+    // skipped (tight_rows), and whole-canvas and slab frames agree instance for instance
+    const float Dlo = D - 1.1e-5f * (g.cxz + cyy) - errD;
+    if (!pd || !fin || !tight_finite(lim) || !(Dlo > 0.25f * D)) { g.mode = 2u; return g; } // non-PD conic, NaN/inf, or cx cz - cy^2 lost to cancellation
+    g.xmax = __builtin_sqrtf(g.lim2 * 1.0001f * cz / Dlo) * 1.0002f + 0.02f;
+    g.ymax = __builtin_sqrtf(g.lim2 * 1.0001f * cx / Dlo) * 1.0002f + 0.02f;
     g.dyR = -cy * g.xmax / cz;
-    g.eR = __builtin_fabsf(g.dyR) * (errD / Dlo + 4.0e-4f) + 0.02f;
-    g.mode = tight_finite(g.xmax) && tight_finite(g.dyR) ? 1u : 2u;
+    g.eR = __builtin_fabsf(g.dyR) * ((D - Dlo) / Dlo + 4.0e-4f) + 0.02f;
+    g.mode = tight_finite(g.xmax) && tight_finite(g.ymax) && tight_finite(g.dyR) ? 1u : 2u;
     return g;
 }
 
@@ -101,74 +105,102 @@ __device__ __forceinline__ bool tight_strip(const TightG& g, float a, float b, b
     return true;
 }
 
-// Columns of width `w` pixels (column c = pixel centres [c w, c w + w - 1]) that the pixel interval [plo, phi] touches,
-// clamped to [cmin, cmax]; empty when lo > hi.
-__device__ __forceinline__ void tight_cols(float plo, float phi, float w, int cmin, int cmax, int& lo, int& hi) {
-    const float inv = 1.0f / w;
-    const float flo = __builtin_ceilf((plo - (w - 1.0f)) * inv), fhi = __builtin_floorf(phi * inv);
+// Columns of width w pixels (inv_w = 1/w, exact: w is a power of two; column c = pixel centres [c w, c w + w - 1]) that the
+// pixel interval [plo, phi] touches, clamped to [cmin, cmax]; empty when lo > hi.
+__device__ __forceinline__ void tight_cols(float plo, float phi, float w, float inv_w, int cmin, int cmax, int& lo, int& hi) {
+    const float flo = __builtin_ceilf((plo - (w - 1.0f)) * inv_w), fhi = __builtin_floorf(phi * inv_w);
     lo = flo <= (float)cmin ? cmin : (flo > (float)cmax ? cmax + 1 : (int)flo);
     hi = fhi >= (float)cmax ? cmax : (fhi < (float)cmin ? cmin - 1 : (int)fhi);
 }
 
-// The tiles of tile row ty that gaussian g is emitted to, for a rect whose slab-clipped columns are [xa, xa + wmain)
-// (slab_cols: real columns only) plus `alias` (the reference's column ntx, which lands in column 0 of the next row).
-// Returns the instance count of the row; tlo..thi = its real tile columns (tlo > thi: none); r.alias = the aliased one is kept.
-struct TightRow { int tlo, thi; uint32_t alias; };
-// Tile columns [cmin, cmax] of tile row ty that intersect E (mode 1); empty: lo > hi.
-__device__ __forceinline__ void tight_row_cols(const TightG& g, uint32_t ty, uint32_t ts, int cmin, int cmax, int& lo, int& hi) {
-    lo = cmax + 1; hi = cmin - 1;
-    const float b = g.gy - (float)(ty * ts), a = g.gy - (float)((ty + 1u) * ts); // pixel rows [ty ts, (ty+1) ts], continuous
-    float lo_a, hi_a, lo_b, hi_b, plo, phi;
-    const bool va = tight_chord(g, a, lo_a, hi_a), vb = tight_chord(g, b, lo_b, hi_b);
-    if (tight_strip(g, a, b, va, lo_a, hi_a, vb, lo_b, hi_b, plo, phi)) tight_cols(plo, phi, (float)ts, cmin, cmax, lo, hi);
+struct TightChord { bool v; float lo, hi; };
+__device__ __forceinline__ TightChord tight_chord_at(const TightG& g, float dy) {
+    TightChord c;
+    c.lo = c.hi = 0.0f;
+    c.v = tight_chord(g, dy, c.lo, c.hi);
+    return c;
 }
-__device__ __forceinline__ uint32_t tight_row(const TightG& g, uint32_t ty, uint32_t ts, uint32_t nty, uint32_t xa, uint32_t wmain,
-                                              uint32_t alias, TightRow& r) {
+// dy of the boundary between tile rows ty-1 and ty (pixel row ty*ts), the same float wherever it is computed
+__device__ __forceinline__ float tight_row_dy(const TightG& g, uint32_t ty, uint32_t ts) { return g.gy - (float)(ty * ts); }
+
+// Tile rows [ra, rb) of the rect's rows [y0, y1) that can hold an instance: the rows E's vertical extent reaches (plus the
+// row above them when the rect has the aliased column, whose instance belongs to the NEXT row's column 0).  Mode 2: all rows.
+__device__ __forceinline__ void tight_rows(const TightG& g, uint32_t y0, uint32_t y1, uint32_t ts, float inv_ts, uint32_t nty, uint32_t alias,
+                                           uint32_t& ra, uint32_t& rb) {
+    if (y1 > nty) y1 = nty; // rows past the grid never reach the blend (compute_ranges ignores tiles >= T)
+    ra = y0; rb = y1 > y0 ? y1 : y0;
+    if (g.mode != 1u) return;
+    const float lo = __builtin_floorf((g.gy - g.ymax) * inv_ts) - (alias ? 1.0f : 0.0f), hi = __builtin_floorf((g.gy + g.ymax) * inv_ts) + 1.0f;
+    if (lo > (float)ra) ra = lo >= (float)rb ? rb : (uint32_t)lo;
+    if (hi < (float)rb) rb = hi <= (float)ra ? ra : (uint32_t)hi;
+}
+
+// The tiles of tile row ty that gaussian g is emitted to, for a rect whose slab-clipped real columns are [xa, xa + wmain)
+// plus `alias` (the reference's column ntx, which lands in column 0 of the next row).  cb / ca: the chords at the
+// row's upper and lower boundary (tight_row_dy(ty), tight_row_dy(ty + 1)).  Returns the instance count of the row;
+// tlo..thi = its real tile columns (tlo > thi: none); r.alias = the aliased instance is kept.
+struct TightRow { int tlo, thi; uint32_t alias; };
+__device__ __forceinline__ uint32_t tight_row(const TightG& g, uint32_t ty, uint32_t ts, float inv_ts, uint32_t nty, uint32_t xa, uint32_t wmain,
+                                              uint32_t alias, const TightChord& cb, const TightChord& ca, TightRow& r) {
     r.tlo = 0; r.thi = -1; r.alias = 0u;
-    if (ty >= nty) return 0u; // rows past the grid never reach the blend (compute_ranges ignores tiles >= T)
+    if (ty >= nty) return 0u;
     if (wmain) {
         if (g.mode == 2u) { r.tlo = (int)xa; r.thi = (int)(xa + wmain) - 1; }
-        else tight_row_cols(g, ty, ts, (int)xa, (int)(xa + wmain) - 1, r.tlo, r.thi);
+        else {
+            float plo, phi;
+            if (tight_strip(g, tight_row_dy(g, ty + 1u, ts), tight_row_dy(g, ty, ts), ca.v, ca.lo, ca.hi, cb.v, cb.lo, cb.hi, plo, phi))
+                tight_cols(plo, phi, (float)ts, inv_ts, (int)xa, (int)(xa + wmain) - 1, r.tlo, r.thi);
+            else { r.tlo = (int)xa; r.thi = (int)xa - 1; }
+        }
     }
-    // the aliased instance of row ty (the reference's column ntx) IS tile (ty + 1, 0): kept if that tile exists and
-    // intersects E -- at the far side of the screen from the gaussian, so almost never
+    // the aliased instance of row ty IS tile (ty + 1, 0): kept if that tile exists and intersects E -- at the far side of the
+    // screen from the gaussian, so almost never
     if (alias && ty + 1u < nty) {
         if (g.mode == 2u) r.alias = 1u;
         else {
-            int lo, hi;
-            tight_row_cols(g, ty + 1u, ts, 0, 0, lo, hi);
+            const TightChord c2 = tight_chord_at(g, tight_row_dy(g, ty + 2u, ts));
+            float plo, phi;
+            int lo = 1, hi = 0;
+            if (tight_strip(g, tight_row_dy(g, ty + 2u, ts), tight_row_dy(g, ty + 1u, ts), c2.v, c2.lo, c2.hi, ca.v, ca.lo, ca.hi, plo, phi))
+                tight_cols(plo, phi, (float)ts, inv_ts, 0, 0, lo, hi);
             r.alias = lo <= hi ? 1u : 0u;
         }
     }
     return (uint32_t)(r.thi >= r.tlo ? r.thi - r.tlo + 1 : 0) + r.alias;
 }
 
-// Sub-block columns (width sub = tile_size/2 pixels, or the whole 8-pixel tile) touched in the upper (s = 0) and lower
-// (s = 1) half strip of tile row ty; empty: lo > hi.  Only used for the masks, never for counts.
-__device__ __forceinline__ void tight_substrips(const TightG& g, uint32_t ty, uint32_t ts, uint32_t sub, int cmin, int cmax, int lo[2],
-                                                int hi[2]) {
-    const uint32_t ns = ts / sub; // 1 or 2
-    lo[0] = lo[1] = cmax + 1; hi[0] = hi[1] = cmin - 1;
-    if (g.mode == 2u) { lo[0] = lo[1] = cmin; hi[0] = hi[1] = cmax; return; }
-    float yb = g.gy - (float)(ty * ts);
-    float lo_b, hi_b;
-    bool vb = tight_chord(g, yb, lo_b, hi_b);
-    for (uint32_t s = 0; s < ns; ++s) {
-        const float ya = g.gy - (float)(ty * ts + (s + 1u) * sub);
-        float lo_a, hi_a, plo, phi;
-        const bool va = tight_chord(g, ya, lo_a, hi_a);
-        if (tight_strip(g, ya, yb, va, lo_a, hi_a, vb, lo_b, hi_b, plo, phi)) tight_cols(plo, phi, (float)sub, cmin, cmax, lo[s], hi[s]);
-        yb = ya; vb = va; lo_b = lo_a; hi_b = hi_a;
-    }
-}
-
-// Tile count of a gaussian under tight binning: rows [y0, y1) of its rect (the reference's rminy .. rmaxy).
-__device__ __forceinline__ uint32_t tight_count(const TightG& g, uint32_t y0, uint32_t y1, uint32_t ts, uint32_t nty, uint32_t xa,
+// Tile count of a gaussian under tight binning: rows [y0, y1) of its rect (the reference's rminy .. rmaxy).  Consecutive rows
+// share a boundary, so one chord (one sqrt) per row.
+__device__ __forceinline__ uint32_t tight_count(const TightG& g, uint32_t y0, uint32_t y1, uint32_t ts, float inv_ts, uint32_t nty, uint32_t xa,
                                                 uint32_t wmain, uint32_t alias) {
     if (g.mode == 0u) return 0u;
-    uint32_t n = 0;
-    if (y1 > nty) y1 = nty;
+    uint32_t ra, rb, n = 0;
+    tight_rows(g, y0, y1, ts, inv_ts, nty, alias, ra, rb);
+    if (ra >= rb) return 0u;
     TightRow r;
-    for (uint32_t ty = y0; ty < y1; ++ty) n += tight_row(g, ty, ts, nty, xa, wmain, alias, r);
+    TightChord cb = tight_chord_at(g, tight_row_dy(g, ra, ts));
+    for (uint32_t ty = ra; ty < rb; ++ty) {
+        const TightChord ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, ts));
+        n += tight_row(g, ty, ts, inv_ts, nty, xa, wmain, alias, cb, ca, r);
+        cb = ca;
+    }
     return n;
+}
+
+// Sub-block columns (width sub = tile_size/2 pixels, or the whole 8-pixel tile) touched in the upper (s = 0) and lower
+// (s = 1) half strip of tile row ty; empty: lo > hi.  cb / ca as in tight_row.  Only the masks use this, never a count.
+__device__ __forceinline__ void tight_substrips(const TightG& g, uint32_t ty, uint32_t ts, uint32_t sub, float inv_sub, int cmin, int cmax,
+                                                const TightChord& cb, const TightChord& ca, int lo[2], int hi[2]) {
+    lo[0] = lo[1] = cmax + 1; hi[0] = hi[1] = cmin - 1;
+    if (g.mode == 2u) { lo[0] = lo[1] = cmin; hi[0] = hi[1] = cmax; return; }
+    const float yb = tight_row_dy(g, ty, ts), ya = tight_row_dy(g, ty + 1u, ts);
+    float plo, phi;
+    if (sub == ts) { // tile 8: the mask is the tile itself
+        if (tight_strip(g, ya, yb, ca.v, ca.lo, ca.hi, cb.v, cb.lo, cb.hi, plo, phi)) tight_cols(plo, phi, (float)sub, inv_sub, cmin, cmax, lo[0], hi[0]);
+        return;
+    }
+    const float ym = g.gy - (float)(ty * ts + sub);
+    const TightChord cm = tight_chord_at(g, ym);
+    if (tight_strip(g, ym, yb, cm.v, cm.lo, cm.hi, cb.v, cb.lo, cb.hi, plo, phi)) tight_cols(plo, phi, (float)sub, inv_sub, cmin, cmax, lo[0], hi[0]);
+    if (tight_strip(g, ya, ym, ca.v, ca.lo, ca.hi, cm.v, cm.lo, cm.hi, plo, phi)) tight_cols(plo, phi, (float)sub, inv_sub, cmin, cmax, lo[1], hi[1]);
 }

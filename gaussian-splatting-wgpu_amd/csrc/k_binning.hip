@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
         total = f.capacity;
     }
     const uint32_t ts = f.tile_size, sub = ts >= 16u ? ts / 2u : ts, ns = ts / sub; // half strips per tile row: 1 (tile 8) or 2
+    const float inv_ts = 1.0f / (float)ts, inv_sub = 1.0f / (float)sub;
     const float Wf = (float)f.width, Hf = (float)f.height;
     const uint32_t nchunks = (total + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT;
     for (uint32_t c = blockIdx.x * 4u + w; c < nchunks; c += gridDim.x * 4u) {
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
             const uint32_t k = kbase + lane;
             uint32_t off = 0xFFFFFFFFu, cnt = 0, nrows = 0, gid = 0, y0b = 0, colsw = 0;
             TightG tg;
-            tg.gx = tg.gy = tg.cx = tg.cy = tg.cz = tg.cxz = tg.lim2 = tg.rcx = tg.xmax = tg.dyR = tg.eR = 0.0f;
+            tg.gx = tg.gy = tg.cx = tg.cy = tg.cz = tg.cxz = tg.lim2 = tg.rcx = tg.xmax = tg.ymax = tg.dyR = tg.eR = 0.0f;
             tg.mode = 0u;
             if (k < nel) {
                 const uint32_t packed = counts[k];
@@ -470,9 +471,10 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
                                      __uint_as_float(r1.z), op, Wf, Hf);
                     uint32_t xa, wmain, alias;
                     slab_cols_emit(r3.x, r3.z, f, xa, wmain, alias);
-                    const uint32_t y1 = r3.w < f.nty ? r3.w : f.nty;
-                    nrows = y1 > r3.y ? y1 - r3.y : 0u;
-                    y0b = r3.y | ((packed >> GS_COUNT_BITS) << 16);
+                    uint32_t ra, rb;
+                    tight_rows(tg, r3.y, r3.w, ts, inv_ts, f.nty, alias, ra, rb); // the rows the projection counted
+                    nrows = rb - ra;
+                    y0b = ra | ((packed >> GS_COUNT_BITS) << 16);
                     colsw = xa | (wmain << 16) | (alias << 31);
                 }
             }
@@ -510,25 +512,27 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
                     const float4 a = S.pA[j], b = S.pB[j], cc = S.pC[j];
                     TightG g;
                     g.gx = a.x; g.gy = a.y; g.cx = a.z; g.cy = a.w; g.cz = b.x; g.cxz = b.y; g.lim2 = b.z; g.rcx = b.w;
-                    g.xmax = cc.x; g.dyR = cc.y; g.eR = cc.z; g.mode = __float_as_uint(cc.w);
+                    g.xmax = cc.x; g.dyR = cc.y; g.eR = cc.z; g.mode = __float_as_uint(cc.w); g.ymax = 0.0f; // (ymax only picks the rows)
                     const uint32_t yb = S.y0b[j], cw = S.cols[j];
                     const uint32_t ty = (yb & 0xFFFFu) + (ri - S.rp[j]);
                     const uint32_t xa = cw & 0xFFFFu, wmain = (cw >> 16) & 0x7FFFu, alias = cw >> 31;
                     TightRow r;
-                    len = tight_row(g, ty, ts, f.nty, xa, wmain, alias, r);
+                    const TightChord cb = tight_chord_at(g, tight_row_dy(g, ty, ts)), ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, ts));
+                    len = tight_row(g, ty, ts, inv_ts, f.nty, xa, wmain, alias, cb, ca, r);
                     mainlen = len - r.alias;
                     rowbase = ty * f.ntx;
                     tlo = (uint32_t)r.tlo;
                     if (mainlen) {
                         int lo[2], hi[2];
                         const int cmin = (int)(tlo * ns), cmax = (int)((tlo + mainlen) * ns) - 1;
-                        tight_substrips(g, ty, ts, sub, cmin, cmax, lo, hi);
+                        tight_substrips(g, ty, ts, sub, inv_sub, cmin, cmax, cb, ca, lo, hi);
                         w0 = (uint32_t)lo[0] | ((uint32_t)(hi[0] + 1) << 16);
                         w1 = (uint32_t)lo[1] | ((uint32_t)(hi[1] + 1) << 16);
                     }
                     if (r.alias) { // its sub-blocks: tile (ty + 1, 0)
                         int lo[2], hi[2];
-                        tight_substrips(g, ty + 1u, ts, sub, 0, (int)ns - 1, lo, hi);
+                        const TightChord c2 = tight_chord_at(g, tight_row_dy(g, ty + 2u, ts));
+                        tight_substrips(g, ty + 1u, ts, sub, inv_sub, 0, (int)ns - 1, ca, c2, lo, hi);
                         am = (uint32_t)(lo[0] <= 0 && 0 <= hi[0]);
                         if (ns == 2u) am |= ((uint32_t)(lo[0] <= 1 && 1 <= hi[0]) << 1) | ((uint32_t)(lo[1] <= 0 && 0 <= hi[1]) << 2) | ((uint32_t)(lo[1] <= 1 && 1 <= hi[1]) << 3);
                     }

@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
     __shared__ uint32_t s_erow[FUSED ? PRE_G : 1]; // xa | wmain<<16 | alias<<31
     __shared__ uint32_t s_eyb[FUSED ? PRE_G : 1];  // y0 | bucket<<16
     __shared__ uint32_t s_misc[8];
+    // TIGHT: the tight tile counts of up to 256 survivors at a time are computed by the whole workgroup, one (survivor, tile
+    // row) item per thread and trip (a lane looping over its own rect's rows would wait for the tallest rect of its wave)
+    __shared__ float4 s_tA[TIGHT ? 256 : 1], s_tB[TIGHT ? 256 : 1], s_tC[TIGHT ? 256 : 1]; // gx gy cx cy | cz cxz lim2 rcx | xmax dyR eR mode
+    __shared__ uint32_t s_trow[TIGHT ? 256 : 1], s_tcol[TIGHT ? 256 : 1], s_trp[TIGHT ? 256 : 1], s_tcnt[TIGHT ? 256 : 1];
+    __shared__ uint32_t s_tw[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t bid = blockIdx.x;
     if (FUSED) { // dynamic workgroup id: a workgroup only ever waits on lower tickets, which are already running
@@ -183,8 +188,12 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
     __syncthreads();
 
     // ---- phases 2 and 3: one survivor per lane ----
-    for (uint32_t v = tid; v < nvis; v += 256) {
-        const uint32_t i = base + s_ids[v];
+    const uint32_t trips = (nvis + 255u) / 256u;
+    for (uint32_t v = tid, trip = 0; TIGHT ? trip < trips : v < nvis; v += 256, ++trip) {
+        // TIGHT: every thread takes every trip (workgroup barriers inside); a thread without a survivor recomputes the
+        // last one and writes nothing
+        const bool active = v < nvis;
+        const uint32_t i = base + s_ids[active ? v : nvis - 1u];
         const float4* rec = s.rec + (uint64_t)i * 16;
         const float x = s.px[i], y = s.py[i], z = s.pz[i];
         float ph[4], pv[4];
@@ -235,6 +244,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         const float det = ca * cc - cb * cb;
         uint32_t count = 0;
         uint32_t rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+        uint32_t t_xa = 0, t_wmain = 0, t_alias = 0;
         float conx = 0.f, cony = 0.f, conz = 0.f, opacity = 0.f;
         if (det != 0.0f) { // :60 (det == 0 -> count 0, nothing written)
             const float det_inv = 1.0f / det;
@@ -254,11 +264,58 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             slab_cols(rminx, rmaxx, f, xa, wmain, alias);
             count = f.full ? (rmaxy - rminy) * (rmaxx - rminx) /* :86 */ : (rmaxy - rminy) * (wmain + alias);
             if (FUSED) s_erow[v] = xa | (wmain << 16) | (alias << 31);
-            if (TIGHT && count) {
+            if (TIGHT) { t_xa = xa; t_wmain = wmain; t_alias = alias; }
+        }
+        if (TIGHT) {
+            const float inv_ts = 1.0f / (float)f.tile_size;
+            if (trip) __syncthreads(); // the previous trip's row items are done with the LDS records
+            uint32_t nrows = 0, ra = 0;
+            if (active && count) {
                 opacity = sigmoid_ref(so.w);
                 const TightG tg = tight_setup(uvx, uvy, conx, cony, conz, opacity, (float)f.width, (float)f.height);
-                count = tight_count(tg, rminy, rmaxy, f.tile_size, f.nty, xa, wmain, alias);
+                if (tg.mode == 0u) count = 0u; // opacity below 1/255: no pixel can pass
+                else {
+                    uint32_t rb;
+                    tight_rows(tg, rminy, rmaxy, f.tile_size, inv_ts, f.nty, t_alias, ra, rb);
+                    nrows = rb - ra;
+                    if (!nrows) count = 0u;
+                    s_tA[tid] = make_float4(tg.gx, tg.gy, tg.cx, tg.cy);
+                    s_tB[tid] = make_float4(tg.cz, tg.cxz, tg.lim2, tg.rcx);
+                    s_tC[tid] = make_float4(tg.xmax, tg.dyR, tg.eR, __uint_as_float(tg.mode));
+                    s_trow[tid] = ra;
+                    s_tcol[tid] = t_xa | (t_wmain << 16) | (t_alias << 31);
+                }
             }
+            s_tcnt[tid] = 0u;
+            const uint32_t rincl = wave_incl_scan(nrows, lane);
+            if (lane == 63) s_tw[w] = rincl;
+            __syncthreads();
+            uint32_t wbase = 0, R = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (k < (int)w) wbase += s_tw[k]; R += s_tw[k]; }
+            s_trp[tid] = wbase + rincl - nrows;
+            __syncthreads();
+            for (uint32_t ri = tid; ri < R; ri += 256) {
+                uint32_t j = 0; // largest j with rp[j] <= ri (row-less survivors share their successor's prefix)
+#pragma unroll
+                for (int step = 128; step >= 1; step >>= 1) {
+                    const uint32_t m = j + step;
+                    if (m < 256u && s_trp[m] <= ri) j = m;
+                }
+                const float4 a = s_tA[j], b = s_tB[j], c4 = s_tC[j];
+                TightG g;
+                g.gx = a.x; g.gy = a.y; g.cx = a.z; g.cy = a.w; g.cz = b.x; g.cxz = b.y; g.lim2 = b.z; g.rcx = b.w;
+                g.xmax = c4.x; g.dyR = c4.y; g.eR = c4.z; g.mode = __float_as_uint(c4.w); g.ymax = 0.0f;
+                const uint32_t cw = s_tcol[j];
+                const uint32_t ty = s_trow[j] + (ri - s_trp[j]);
+                TightRow r;
+                const TightChord cb = tight_chord_at(g, tight_row_dy(g, ty, f.tile_size)), ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, f.tile_size));
+                const uint32_t len = tight_row(g, ty, f.tile_size, inv_ts, f.nty, cw & 0xFFFFu, (cw >> 16) & 0x7FFFu, cw >> 31, cb, ca, r);
+                if (len) atomicAdd(&s_tcnt[j], len);
+            }
+            __syncthreads();
+            if (count) count = s_tcnt[tid];
+            if (!active) continue; // (after the last barrier of the trip)
         }
         // low 22 bits: tile count; high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
         const uint32_t bucket = f2u_sat(wg_min(50.0f * pv[2], 999.0f));

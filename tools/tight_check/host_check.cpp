@@ -43,16 +43,20 @@ int main(int argc, char** argv) {
             TightG tg = tight_setup(F(0), F(1), F(4), F(5), F(6), F(11), (float)W, (float)H);
             const uint32_t rx0 = o[12], ry0 = o[13], rx1 = o[14], ry1 = o[15];
             const uint32_t hi = rx1 < ntx ? rx1 : ntx, xa = rx0, wmain = hi > xa ? hi - xa : 0, alias = (rx1 == ntx + 1);
-            const uint32_t cnt = tight_count(tg, ry0, ry1, ts, nty, xa, wmain, alias);
+            const float inv_ts = 1.0f / (float)ts, inv_sub = 1.0f / (float)sub;
+            const uint32_t cnt = tight_count(tg, ry0, ry1, ts, inv_ts, nty, xa, wmain, alias);
             uint32_t got = 0;
-            if (tg.mode != 0)
-                for (uint32_t ty = ry0; ty < ry1 && ty < nty; ++ty) {
+            if (tg.mode != 0) {
+                uint32_t ra, rb;
+                tight_rows(tg, ry0, ry1, ts, inv_ts, nty, alias, ra, rb);
+                for (uint32_t ty = ra; ty < rb; ++ty) {
                     TightRow r;
-                    got += tight_row(tg, ty, ts, nty, xa, wmain, alias, r);
+                    const TightChord cb = tight_chord_at(tg, tight_row_dy(tg, ty, ts)), ca = tight_chord_at(tg, tight_row_dy(tg, ty + 1, ts));
+                    got += tight_row(tg, ty, ts, inv_ts, nty, xa, wmain, alias, cb, ca, r);
                     if (r.thi >= r.tlo) {
                         int lo[2], hi2[2];
                         const int cmin = r.tlo * (int)ns, cmax = (r.thi + 1) * (int)ns - 1;
-                        tight_substrips(tg, ty, ts, sub, cmin, cmax, lo, hi2);
+                        tight_substrips(tg, ty, ts, sub, inv_sub, cmin, cmax, cb, ca, lo, hi2);
                         for (int tc = r.tlo; tc <= r.thi; ++tc) {
                             uint32_t m;
                             if (ns == 2) {
@@ -65,12 +69,14 @@ int main(int argc, char** argv) {
                     }
                     if (r.alias) {
                         int lo[2], hi2[2];
-                        tight_substrips(tg, ty + 1, ts, sub, 0, (int)ns - 1, lo, hi2);
+                        const TightChord c2 = tight_chord_at(tg, tight_row_dy(tg, ty + 2, ts));
+                        tight_substrips(tg, ty + 1, ts, sub, inv_sub, 0, (int)ns - 1, ca, c2, lo, hi2);
                         uint32_t am = (lo[0] <= 0 && 0 <= hi2[0]);
                         if (ns == 2) am |= ((lo[0] <= 1 && 1 <= hi2[0]) << 1) | ((lo[1] <= 0 && 0 <= hi2[1]) << 2) | ((lo[1] <= 1 && 1 <= hi2[1]) << 3);
                         sets[g][ty * ntx + ntx] |= 0x100 | am;
                     }
                 }
+            }
             if (got != cnt) { printf("count mismatch g=%u %u vs %u\n", g, got, cnt); return 1; }
             total_tight += cnt;
         }
