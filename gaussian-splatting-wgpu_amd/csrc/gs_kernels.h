@@ -11,13 +11,13 @@ void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame
 uint32_t gs_scan_blocks(uint32_t n);
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
                     uint32_t* vkey, uint32_t* vval, uint32_t* chunk_table, uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
-                    GsControl* ctl, uint32_t write_totals, hipStream_t st);
+                    GsControl* ctl, uint32_t write_totals, hipStream_t st, uint32_t* ccounts = nullptr, uint32_t* coffsets = nullptr);
 uint64_t gs_emit_chunks(uint64_t capacity);
 // counts: tile-count words in the SAME order as offsets/perm (sorted order)
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                              const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
                              uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st);
-// tight binning (gs_tight.h): counts are the projection's tight tile counts; by_index: elements are all N gaussians in index order
+// tight binning (gs_tight.h): counts / offsets / perm describe the visible gaussians in emission order (index or depth order)
 void gs_launch_emit_tight(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                           const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
                           uint32_t hist_bits, uint32_t hist_passes, bool keys16, bool by_index, hipStream_t st);

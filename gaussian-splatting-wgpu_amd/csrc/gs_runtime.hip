@@ -373,11 +373,14 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     if (fused) {
     } else if (by_index) {
         // the reference's order: scan counts in gaussian order, emit in gaussian order, sort by the full key
-        gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, tight ? c->chunk_table : nullptr,
-                       tight ? (uint32_t)gs_emit_chunks(c->capacity) : 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        if (tight) // the scan also compacts the visible gaussians (ids, counts, offsets): the emission walks only those
+            gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, c->chunk_table, (uint32_t)gs_emit_chunks(c->capacity),
+                           c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st, c->scounts, c->offsets);
+        else
+            gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         mark(c, 2);
         if (tight)
-            gs_launch_emit_tight(c->gdata, c->counts, c->offsets, nullptr, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, 8u, 0u,
+            gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, c->vvalA, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, 8u, 0u,
                                  false, /*by_index=*/true, st);
         else
             gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);

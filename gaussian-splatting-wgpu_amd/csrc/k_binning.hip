@@ -63,7 +63,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ vkey,
                                                        uint32_t* __restrict__ vval, uint32_t* __restrict__ chunk_table,
                                                        uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
-                                                       GsControl* ctl, uint32_t write_totals) {
+                                                       GsControl* ctl, uint32_t write_totals, uint32_t* __restrict__ ccounts,
+                                                       uint32_t* __restrict__ coffsets) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_wsum[SCAN_WAVES];
     __shared__ uint32_t s_wnz[SCAN_WAVES];
@@ -153,18 +154,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
     __syncthreads();
     run = sat_add(run, s_prefix[0]);
     run_nz += s_prefix[1];
+    const uint32_t first_nz = run_nz;
     if (vkey) { // ordered compaction of the elements with a non-zero tile count
         // ... and the digit histograms of the gaussian-level sort that follows (two 5-bit digits of the bucket):
         // per-workgroup LDS counters, one global atomic per non-empty bin
         if (tid < 64u) s_gh[tid] = 0u;
         __syncthreads();
+        uint32_t roff = run;
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) {
             if ((v[j] & GS_COUNT_MASK) != 0u) {
                 const uint32_t bucket = v[j] >> GS_COUNT_BITS;
                 vkey[run_nz] = bucket;
                 vval[run_nz] = base + j;
+                if (ccounts) { // the compacted list with its own counts and offsets: what an emission in index order walks
+                    ccounts[run_nz] = v[j];
+                    coffsets[run_nz] = roff;
+                }
                 ++run_nz;
+                roff += v[j] & GS_COUNT_MASK;
                 atomicAdd(&s_gh[bucket & 31u], 1u);
                 atomicAdd(&s_gh[32u + ((bucket >> 5) & 31u)], 1u);
             }
@@ -172,14 +180,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
         __syncthreads();
         if (tid < 64u && s_gh[tid]) atomicAdd(&ctl->ghist[tid >> 5][tid & 31u], s_gh[tid]);
     }
-    if (chunk_table) {
-        uint32_t r2 = run;
+    if (chunk_table) { // (with ccounts: positions in the compacted list, otherwise element indices)
+        uint32_t r2 = run, knz = first_nz;
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) {
             const uint32_t cnt = v[j] & GS_COUNT_MASK;
             if (cnt) {
                 const uint32_t last = (r2 + cnt - 1u) >> EMIT_CHUNK_SHIFT;
-                for (uint32_t c = (r2 + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT; c <= last && c < chunk_cap; ++c) chunk_table[c] = base + j;
+                for (uint32_t c = (r2 + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT; c <= last && c < chunk_cap; ++c) chunk_table[c] = ccounts ? knz : base + j;
+                ++knz;
             }
             r2 += cnt;
         }
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
 //               builds the sub-block mask from the two half-strip intervals of the row and stores (tile id, id | mask << 28).
 // The order of a gaussian's instances is free (a stable sort by tile follows and a gaussian meets a tile at most once,
 // the aliased duplicate excepted, which is identical); only the order of the gaussians matters, and that is `perm`'s.
-// perm == nullptr: gaussian-index order (the elements are all N gaussians, culled ones have count 0).
+// by_index: the list is in gaussian-index order (reference order): the keys are the full tile*1000 + bucket sort words.
 // ------------------------------------------------------------------------------------------------
 struct EmitTightWave {
     uint32_t off[64], rp[64], run[64], gid[64], y0b[64], cols[64];
@@ -425,7 +434,7 @@ struct EmitTightWave {
     uint32_t incl[64], slot[64], rowbase[64], tlo[64], first[64], s0[64], s1[64], rgid[64], rbucket[64], amask[64];
 };
 
-__global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
+__global__ __launch_bounds__(256, 5) void gs_emit_tight_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
                                                              const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
                                                              const uint32_t* __restrict__ chunk_table, GsFrame f,
                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ values, GsControl* ctl,
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
     const uint32_t hmask = (1u << hist_bits) - 1u;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     EmitTightWave& S = s_w[w];
-    const uint32_t nel = by_index ? f.n : ctl->num_visible; // elements of the emission order
+    const uint32_t nel = ctl->num_visible; // elements of the emission order: the visible gaussians (index or depth order)
     uint32_t total = ctl->num_intersections;
     if (total > f.capacity) { // the frame does not fit: flag it, emit what fits (gs_wait grows and re-renders)
         if (tid == 0 && blockIdx.x == 0) ctl->overflow = 1u;
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(256) void gs_emit_tight_kernel(const uint4* __restr
     const float inv_ts = 1.0f / (float)ts, inv_sub = 1.0f / (float)sub;
     const float Wf = (float)f.width, Hf = (float)f.height;
     const uint32_t nchunks = (total + EMIT_CHUNK - 1u) >> EMIT_CHUNK_SHIFT;
+    // (static split: 18 000 chunks drawn from ONE ticket word cost 200 us -- a hot word serves ~88 atomics per microsecond)
     for (uint32_t c = blockIdx.x * 4u + w; c < nchunks; c += gridDim.x * 4u) {
         const uint32_t S0 = c * EMIT_CHUNK;
         const uint32_t S1 = (c + 1u) * EMIT_CHUNK < total ? (c + 1u) * EMIT_CHUNK : total;
@@ -740,11 +750,11 @@ void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const u
 uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
                     uint32_t* vkey, uint32_t* vval, uint32_t* chunk_table, uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
-                    GsControl* ctl, uint32_t write_totals, hipStream_t st) {
+                    GsControl* ctl, uint32_t write_totals, hipStream_t st, uint32_t* ccounts, uint32_t* coffsets) {
     const uint32_t blocks = gs_scan_blocks(n_static);
     if (!blocks) return;
     hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(SCAN_THREADS), 0, st, counts, gather, n_dev, n_static, offsets, vkey, vval, chunk_table,
-                       chunk_cap, status, ticket, ctl, write_totals);
+                       chunk_cap, status, ticket, ctl, write_totals, ccounts, coffsets);
 }
 uint64_t gs_emit_chunks(uint64_t capacity) { return (capacity >> EMIT_CHUNK_SHIFT) + 2; }
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,

@@ -587,52 +587,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 }
             }
         };
-        // Two-deep software pipeline of the same loop (fused mode, no non-PD survivor in the batch): the LDS broadcast of the
-        // NEXT survivor is issued before the current one is evaluated, in two alternating register sets (no copies).  A wave
-        // alone on its SIMD -- the last third of the launch, when the grid has drained -- is bound by the latency of one
-        // entry's chain (LDS read -> quadratic -> exp -> T update), and this takes the LDS read out of it.
-        auto walk2 = [&]() {
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            // volatile + the asm pins keep the compiler from sinking a broadcast back down to its use (it does, otherwise)
-            auto ld = [&](f32x4& a, f32x4& b, float& c) { // unconditional (slot 0 when nothing is left): the waits stay countable
-                const uint32_t e = m ? (uint32_t)__builtin_ctzll(m) : 0u;
-                m &= m - 1ull;
-                a = *reinterpret_cast<volatile f32x4*>(&sP0[e]);
-                b = *reinterpret_cast<volatile f32x4*>(&sP1[e]);
-                c = *reinterpret_cast<volatile float*>(&sP2[e].x);
-            };
-            auto ev = [&](f32x4& p0, f32x4& p1, float& colb) {
-                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(colb));
-                const float dx = p0.x - pxf, dy = p0.y - pyf;
-                const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
-                const float v = __builtin_fmaf(p1.z * dy, dy, p1.w);
-                const float pw = __builtin_fmaf(dx, u, v);
-                const float alpha = __builtin_fminf(0.99f, __builtin_amdgcn_exp2f(pw));
-                const float test = __builtin_fmaf(-T, alpha, T);
-                const bool keep = (alpha >= c255) && (test >= 0.0001f);
-                const float wgt = (keep ? alpha : 0.0f) * T;
-                cr = __builtin_fmaf(p0.z, wgt, cr);
-                cg = __builtin_fmaf(p0.w, wgt, cg);
-                cb = __builtin_fmaf(colb, wgt, cb);
-                T = keep ? test : T;
-            };
-            f32x4 a0, a1, b0, b1;
-            float ac, bc;
-            if (!m) return;
-            ld(a0, a1, ac);
-            for (;;) {
-                const bool moreB = m != 0ull;
-                ld(b0, b1, bc);
-                ev(a0, a1, ac);
-                if (!moreB) break;
-                const bool moreA = m != 0ull;
-                ld(a0, a1, ac);
-                ev(b0, b1, bc);
-                if (!moreA) break;
-            }
-        };
         if (EXACT || __ballot(npd) != 0ull) walk(std::true_type{});
-        else if (dbg & 32u) walk2();
         else walk(std::false_type{});
         if (EXACT) done = outside || (T * (1.0f - c255) < 0.0001f);
         else done = outside || (__builtin_fmaf(-T, c255, T) < 0.0001f);

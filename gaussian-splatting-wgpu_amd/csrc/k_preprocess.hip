@@ -88,6 +88,42 @@ __device__ __forceinline__ float sigmoid_ref(float o) {
     return (cond * (1.0f / (1.0f + gs_exp(-o)))) + ((1.0f - cond) * (ez / (1.0f + ez)));
 }
 
+// compute_color_from_sh (:240-280): the view direction's SH basis times the 16 RGB coefficients of the record, + 0.5, clamped.
+__device__ __forceinline__ void sh_colour(const float4* __restrict__ rec, float x, float y, float z, const GsUniforms& u, float col[3]) {
+    const float dx = x - u.cam[0], dy = y - u.cam[1], dz = z - u.cam[2];
+    const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float X = dx / dl, Y = dy / dl, Z = dz / dl;
+    const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, xz = X * Z, yz = Y * Z;
+    float k[16];
+    k[4] = 1.0925484305920792f * xy;
+    k[5] = -1.0925484305920792f * yz;
+    k[6] = 0.31539156525252005f * ((2.f * zz - xx) - yy);
+    k[7] = -1.0925484305920792f * xz;
+    k[8] = 0.5462742152960396f * (xx - yy);
+    k[9] = (-0.5900435899266435f * Y) * (3.f * xx - yy);
+    k[10] = (2.890611442640554f * xy) * Z;
+    k[11] = (-0.4570457994644658f * Y) * ((4.f * zz - xx) - yy);
+    k[12] = (0.3731763325901154f * Z) * ((2.f * zz - 3.f * xx) - 3.f * yy);
+    k[13] = (-0.4570457994644658f * X) * ((4.f * zz - xx) - yy);
+    k[14] = (1.445305721320277f * Z) * (xx - yy);
+    k[15] = (-0.5900435899266435f * X) * (xx - 3.f * yy);
+    float shv[48];
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+        const float4 vv = rec[2 + p];
+        shv[4 * p + 0] = vv.x; shv[4 * p + 1] = vv.y; shv[4 * p + 2] = vv.z; shv[4 * p + 3] = vv.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float res = 0.28209479177387814f * shv[c];
+        res = res + 0.4886025119029199f * ((((-Y) * shv[3 + c]) + Z * shv[6 + c]) - X * shv[9 + c]);
+#pragma unroll
+        for (int j = 4; j < 16; ++j) res = res + k[j] * shv[3 * j + c];
+        res = res + 0.5f;
+        col[c] = wg_max(res, 0.0f);
+    }
+}
+
 #define PRE_G 512 // gaussians per workgroup
 #ifndef PRE_WAVES
 #define PRE_WAVES 4 // waves per SIMD the register allocator must leave room for
@@ -327,39 +363,8 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         if (count == 0) continue; // det == 0, or (slab mode) no instance in this rank's tile columns
 
         // ---- phase 3: colour (:240-280) and opacity (:282-294) ----
-        const float dx = x - u.cam[0], dy = y - u.cam[1], dz = z - u.cam[2];
-        const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
-        const float X = dx / dl, Y = dy / dl, Z = dz / dl;
-        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, xz = X * Z, yz = Y * Z;
-        float k[16];
-        k[4] = 1.0925484305920792f * xy;
-        k[5] = -1.0925484305920792f * yz;
-        k[6] = 0.31539156525252005f * ((2.f * zz - xx) - yy);
-        k[7] = -1.0925484305920792f * xz;
-        k[8] = 0.5462742152960396f * (xx - yy);
-        k[9] = (-0.5900435899266435f * Y) * (3.f * xx - yy);
-        k[10] = (2.890611442640554f * xy) * Z;
-        k[11] = (-0.4570457994644658f * Y) * ((4.f * zz - xx) - yy);
-        k[12] = (0.3731763325901154f * Z) * ((2.f * zz - 3.f * xx) - 3.f * yy);
-        k[13] = (-0.4570457994644658f * X) * ((4.f * zz - xx) - yy);
-        k[14] = (1.445305721320277f * Z) * (xx - yy);
-        k[15] = (-0.5900435899266435f * X) * (xx - 3.f * yy);
-        float shv[48];
-#pragma unroll
-        for (int p = 0; p < 12; ++p) {
-            const float4 vv = rec[2 + p];
-            shv[4 * p + 0] = vv.x; shv[4 * p + 1] = vv.y; shv[4 * p + 2] = vv.z; shv[4 * p + 3] = vv.w;
-        }
         float col[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float res = 0.28209479177387814f * shv[c];
-            res = res + 0.4886025119029199f * ((((-Y) * shv[3 + c]) + Z * shv[6 + c]) - X * shv[9 + c]);
-#pragma unroll
-            for (int j = 4; j < 16; ++j) res = res + k[j] * shv[3 * j + c];
-            res = res + 0.5f;
-            col[c] = wg_max(res, 0.0f);
-        }
+        sh_colour(rec, x, y, z, u, col);
         if (!TIGHT) opacity = sigmoid_ref(so.w);
         // GaussianData record (:97-104), 64 B as four 16-byte stores
         uint4* o4 = gdata + (uint64_t)i * 4;
