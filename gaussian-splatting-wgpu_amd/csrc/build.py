@@ -14,7 +14,7 @@ ARCH = "gfx950"
 # fused operations are spelled __builtin_fmaf where they are wanted.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
-SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
+SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_gsort.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
 
 
 def _stale(target, deps):
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     so = os.path.join(OUT, "libgsplat_hip.so")
     if force or _stale(so, objs):

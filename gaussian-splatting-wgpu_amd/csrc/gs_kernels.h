@@ -40,3 +40,8 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
 void gs_launch_debug_view(const uint32_t* ranges, const GsFrame& f, uint32_t view, uint32_t* rgba8, hipStream_t st);
 void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t height, const uint32_t* d_px_bounds, uint32_t n_slabs,
                         uint64_t slab_stride_px, hipStream_t st);
+// k_gsort.hip: the visible gaussians sorted by depth bucket (stable) with their tile counts scanned in that order
+uint32_t gs_gsort_tiles(uint32_t n);
+uint64_t gs_gsort_scratch_bytes(uint32_t n);
+void gs_launch_gsort(const uint32_t* ids, const uint32_t* words, const GsControl* ctl, uint32_t n_max, void* scratch, uint32_t* perm,
+                     uint32_t* scounts, uint32_t* offsets, uint32_t* chunk_table, uint32_t chunk_cap, hipStream_t st);

@@ -86,6 +86,8 @@ struct gs_ctx {
     uint32_t* sort_status = nullptr;            // instance sort
     uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
     uint32_t* scounts = nullptr;                // tile-count words of the visible gaussians in depth-sorted order
+    void* gsort_scratch = nullptr;              // (bucket, tile) table of the gaussian-level counting sort (k_gsort.hip)
+    bool old_gsort = false;                     // GS_OPT_BLEND_ABLATION bit 18 (profiling): round 1's two look-back sweeps + second scan
     bool scene_borrowed = false;                // gs_share_splats: scene_mem belongs to another context
     uint32_t last_passes = 0;
     bool last_by_index = true;
@@ -236,7 +238,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     free_kv(c);
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
+    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts); hipFree(c->gsort_scratch);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky); hipFree(c->blend_prof);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_sticky) hipHostFree(c->h_sticky);
@@ -253,8 +255,8 @@ GS_EXPORT int32_t gs_wait(gs_ctx* c);
 static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity = 0) {
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts);
-    c->scounts = nullptr;
+    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts); hipFree(c->gsort_scratch);
+    c->scounts = nullptr; c->gsort_scratch = nullptr;
     c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
     c->vkeyA = c->vvalA = c->vkeyB = c->vvalB = nullptr;
     c->scene_borrowed = false;
@@ -269,6 +271,7 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity =
     HIP_TRY(hipMalloc((void**)&c->vkeyB, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->vvalB, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->scounts, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc(&c->gsort_scratch, gs_gsort_scratch_bytes((uint32_t)n)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
     uint64_t cap = c->cfg.max_intersections ? c->cfg.max_intersections : std::max<uint64_t>(4 * n, 1u << 22);
@@ -389,14 +392,24 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         // gaussian index).  Sorting the N_vis visible GAUSSIANS by bucket first (stable, 10 bits, ~16x fewer elements
         // than instances) and emitting their instances in that order leaves only the tile id for the stable instance
         // sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
-        gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
         uint32_t *gk = nullptr, *gperm = nullptr;
-        // the last gaussian-level sweep also gathers the tile-count words into sorted order (c->scounts), so the second
-        // scan and the emission read them coalesced
-        gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
-                       c->n, 2, 5, 0, c->gsort_status, c->grid_persist, /*have_hist=*/true, c->counts, c->scounts, st, &gk, &gperm);
-        gs_launch_scan(c->scounts, nullptr, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table,
-                       (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
+        if (!c->old_gsort) {
+            // the scan compacts the visible gaussians (ids + count words); ONE stable 10-bit counting sort then gives them in
+            // (bucket, index) order together with the prefix of their tile counts and the emission's chunk table (k_gsort.hip)
+            gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st,
+                           c->vkeyB, nullptr);
+            gs_launch_gsort(c->vvalA, c->vkeyB, c->ctl, c->n, c->gsort_scratch, c->vvalB, c->scounts, c->offsets, c->chunk_table,
+                            (uint32_t)gs_emit_chunks(c->capacity), st);
+            gperm = c->vvalB;
+        } else {
+            gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+            // the last gaussian-level sweep also gathers the tile-count words into sorted order (c->scounts), so the second
+            // scan and the emission read them coalesced
+            gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
+                           c->n, 2, 5, 0, c->gsort_status, c->grid_persist, /*have_hist=*/true, c->counts, c->scounts, st, &gk, &gperm);
+            gs_launch_scan(c->scounts, nullptr, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table,
+                           (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
+        }
         mark(c, 2);
         if (tight)
             gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
@@ -679,7 +692,7 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
 GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: null ctx");
     switch (key) {
-    case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value; return GS_OK;
+    case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value & 0x3FFFFu; c->old_gsort = ((uint32_t)value & 0x40000u) != 0; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; c->max_I_seen = 0; c->truncated_frames = 0; return GS_OK;
     case GS_OPT_EMIT_ORDER: if (value < 0 || value > 2) break; c->emit_order = (int)value; return GS_OK;

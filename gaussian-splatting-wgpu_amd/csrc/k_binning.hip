@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
                 vval[run_nz] = base + j;
                 if (ccounts) { // the compacted list with its own counts and offsets: what an emission in index order walks
                     ccounts[run_nz] = v[j];
-                    coffsets[run_nz] = roff;
+                    if (coffsets) coffsets[run_nz] = roff;
                 }
                 ++run_nz;
                 roff += v[j] & GS_COUNT_MASK;
