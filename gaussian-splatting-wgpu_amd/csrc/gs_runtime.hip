@@ -40,6 +40,29 @@ static int32_t fail(int32_t code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                                             \
     } while (0)
 
+// roctx ranges named after the reference's stages (renderer.ts:406,421,467,477,501,546), opened around the launches of each
+// stage when GS_FLAG_TIMING is set, so a rocprofv3 --marker-trace lines up with the reference's own console.log timings.
+// The library is looked up at run time: no link dependency, silently absent when the profiler SDK is not installed.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+        if (h) {
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (!push || !pop) push = nullptr, pop = nullptr;
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+const char* const kStageRange[] = {"gsplat:process_gaussians", "gsplat:exclusive_scan", "gsplat:write_tile_ids", "gsplat:radix_sort",
+                                   "gsplat:compute_ranges", "gsplat:compute_tiles"};
+}
+
 #define GS_EV_RING 256
 struct gs_ctx {
     gs_config cfg{};
@@ -337,8 +360,14 @@ GS_EXPORT int32_t gs_upload_splats(gs_ctx* c, const void* aos, uint64_t n) {
     return rc;
 }
 
-static inline void mark(gs_ctx* c, int i) {
-    if (c->have_events) hipEventRecord(c->ev[c->frames % GS_EV_RING][i], c->stream);
+static inline void mark(gs_ctx* c, int i) { // stage boundary i: closes stage i-1, opens stage i
+    if (!c->have_events) return;
+    hipEventRecord(c->ev[c->frames % GS_EV_RING][i], c->stream);
+    Roctx& r = roctx();
+    if (r.push) {
+        if (i > 0) r.pop();
+        if (i < GS_STAGE_COUNT) r.push(kStageRange[i]);
+    }
 }
 
 static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8) {

@@ -51,19 +51,43 @@ static int get_u32_prop(napi_env env, napi_value obj, const char* name, uint32_t
     return 1;
 }
 
-static gs_ctx* unwrap(napi_env env, napi_value v) {
+/* The external holds a box so that destroy() can null the context.  A gs_ctx is not re-entrant and renderAsync() works on it
+ * from a libuv worker: while a frame is in flight (`busy`) every other call on the handle is refused, and destroy() is
+ * deferred to the frame's completion (all of this happens on the JS thread, so the flags need no lock). */
+typedef struct {
+    gs_ctx* ctx;
+    int busy;            /* a renderAsync job owns the context */
+    int destroy_pending; /* destroy() was called meanwhile */
+} ctx_box;
+
+static ctx_box* unbox(napi_env env, napi_value v) {
     void* p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
         napi_throw_type_error(env, NULL, "gsplat: expected a context handle");
         return NULL;
     }
-    return *(gs_ctx**)p; /* the external holds a box so destroy() can null it */
+    return (ctx_box*)p;
+}
+
+static gs_ctx* unwrap(napi_env env, napi_value v) {
+    ctx_box* b = unbox(env, v);
+    if (!b) return NULL;
+    if (!b->ctx) {
+        napi_throw_error(env, NULL, "gsplat: the context has been destroyed");
+        return NULL;
+    }
+    if (b->busy) {
+        napi_throw_error(env, NULL, "gsplat: a frame is in flight on this context (await renderAsync first)");
+        return NULL;
+    }
+    return b->ctx;
 }
 
 static void finalize_ctx(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
-    gs_ctx** box = (gs_ctx**)data;
-    if (*box) gs_destroy(*box);
+    ctx_box* box = (ctx_box*)data;
+    if (box->busy) { box->destroy_pending = 2; return; } /* the job frees the box when it completes */
+    if (box->ctx) gs_destroy(box->ctx);
     free(box);
 }
 
@@ -107,10 +131,16 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
     gs_ctx* ctx = NULL;
     int32_t rc = gs_create(&cfg, &ctx);
     if (rc != GS_OK) return throw_gs(env, rc);
-    gs_ctx** box = (gs_ctx**)malloc(sizeof(gs_ctx*));
-    *box = ctx;
+    ctx_box* box = (ctx_box*)calloc(1, sizeof(ctx_box));
+    if (!box) { gs_destroy(ctx); napi_throw_error(env, NULL, "gsplat.create: out of memory"); return NULL; }
+    box->ctx = ctx;
     napi_value ext;
-    NAPI_CALL(env, napi_create_external(env, box, finalize_ctx, NULL, &ext));
+    if (napi_create_external(env, box, finalize_ctx, NULL, &ext) != napi_ok) {
+        gs_destroy(ctx);
+        free(box);
+        napi_throw_error(env, NULL, "N-API call failed: napi_create_external");
+        return NULL;
+    }
     return ext;
 }
 
@@ -120,10 +150,14 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
     NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     void* p = NULL;
     if (argc < 1 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p) return NULL;
-    gs_ctx** box = (gs_ctx**)p;
-    if (*box) {
-        gs_destroy(*box);
-        *box = NULL;
+    ctx_box* box = (ctx_box*)p;
+    if (box->busy) { /* a frame is in flight on a worker: destroy when it completes */
+        if (!box->destroy_pending) box->destroy_pending = 1;
+        return NULL;
+    }
+    if (box->ctx) {
+        gs_destroy(box->ctx);
+        box->ctx = NULL;
     }
     return NULL;
 }
@@ -138,8 +172,8 @@ static napi_value js_upload(napi_env env, napi_callback_info info) {
     void* data = NULL;
     size_t len = 0;
     double n = 0;
-    if (!get_bytes(env, argv[1], &data, &len) || napi_get_value_double(env, argv[2], &n) != napi_ok ||
-        (double)len < n * GS_SPLAT_RECORD_BYTES) {
+    if (!get_bytes(env, argv[1], &data, &len) || napi_get_value_double(env, argv[2], &n) != napi_ok || !(n >= 0.0) ||
+        n != (double)(uint64_t)n || n >= 2147483648.0 || (double)len < n * GS_SPLAT_RECORD_BYTES) {
         napi_throw_type_error(env, NULL, "gsplat.uploadSplats: need n*320 bytes");
         return NULL;
     }
@@ -183,6 +217,7 @@ static napi_value js_render_sync(napi_env env, napi_callback_info info) {
 typedef struct {
     napi_async_work work;
     napi_deferred deferred;
+    ctx_box* box;
     gs_ctx* ctx;
     unsigned char uniforms[GS_UNIFORM_BYTES];
     int32_t rc;
@@ -203,6 +238,14 @@ static void job_execute(napi_env env, void* data) {
 static void job_complete(napi_env env, napi_status status, void* data) {
     frame_job* j = (frame_job*)data;
     napi_value v;
+    ctx_box* box = j->box;
+    box->busy = 0;
+    if (box->destroy_pending) { /* destroy() (1) or the finalizer (2) came while the frame was in flight */
+        if (box->ctx) gs_destroy(box->ctx);
+        box->ctx = NULL;
+        if (box->destroy_pending == 2) free(box);
+        else box->destroy_pending = 0;
+    }
     if (status == napi_ok && j->rc == GS_OK) {
         napi_get_undefined(env, &v);
         napi_resolve_deferred(env, j->deferred, v);
@@ -230,13 +273,26 @@ static napi_value js_render_async(napi_env env, napi_callback_info info) {
         return NULL;
     }
     frame_job* j = (frame_job*)calloc(1, sizeof(frame_job));
+    if (!j) { napi_throw_error(env, NULL, "gsplat.renderAsync: out of memory"); return NULL; }
+    j->box = unbox(env, argv[0]);
     j->ctx = ctx;
     memcpy(j->uniforms, data, GS_UNIFORM_BYTES);
     napi_value promise, name;
-    NAPI_CALL(env, napi_create_promise(env, &j->deferred, &promise));
-    NAPI_CALL(env, napi_create_string_utf8(env, "gsplat.frame", NAPI_AUTO_LENGTH, &name));
-    NAPI_CALL(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
-    NAPI_CALL(env, napi_queue_async_work(env, j->work));
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "gsplat.frame", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work) != napi_ok) {
+        free(j);
+        napi_throw_error(env, NULL, "gsplat.renderAsync: N-API call failed");
+        return NULL;
+    }
+    j->box->busy = 1;
+    if (napi_queue_async_work(env, j->work) != napi_ok) {
+        j->box->busy = 0;
+        napi_delete_async_work(env, j->work);
+        free(j);
+        napi_throw_error(env, NULL, "gsplat.renderAsync: napi_queue_async_work failed");
+        return NULL;
+    }
     return promise;
 }
 
@@ -302,6 +358,12 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
     set_num(env, o, "sortPasses", (double)st.sort_passes);
     set_num(env, o, "frames", (double)st.frames);
     set_num(env, o, "frameUs", (double)st.frame_us);
+    set_num(env, o, "numEvaluated", (double)st.num_evaluated);
+    set_num(env, o, "depthOrdered", (double)st.depth_ordered);
+    set_num(env, o, "tightBinning", (double)st.tight_binning);
+    set_num(env, o, "capacity", (double)st.capacity);
+    set_num(env, o, "maxIntersectionsSeen", (double)st.max_intersections_seen);
+    set_num(env, o, "truncatedFrames", (double)st.truncated_frames);
     NAPI_CALL(env, napi_create_array_with_length(env, GS_STAGE_COUNT, &arr));
     for (uint32_t i = 0; i < GS_STAGE_COUNT; ++i) {
         napi_value n;

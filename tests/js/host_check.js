@@ -67,6 +67,39 @@ async function main() {
     for (let i = 0; same && i < pa.length; ++i) same = pa[i] === pb[i];
     await b.destroy(); await a.destroy();
     console.log(JSON.stringify({ same, bytes: pa.length }));
+  } else if (cmd === 'ppm') {
+    // ppm <out.ppm> <W> <H>: a known rgba pattern through the presentation sink
+    const W = parseInt(process.argv[4], 10), H = parseInt(process.argv[5], 10);
+    const rgba = new Uint8Array(W * H * 4);
+    for (let i = 0; i < W * H; ++i) { rgba[4 * i] = i & 255; rgba[4 * i + 1] = (i >> 3) & 255; rgba[4 * i + 2] = (7 * i) & 255; rgba[4 * i + 3] = 255; }
+    g.writePPM(process.argv[3], rgba, W, H);
+    console.log(JSON.stringify({ ok: true }));
+  } else if (cmd === 'camfile') {
+    // camfile <cameras.json>: the reference's CameraFileParser list (camera.ts:344-400) without the DOM
+    const list = g.loadCameraFile(process.argv[3], { width: 800, height: 800 });
+    console.log(JSON.stringify(list.map((e) => ({ name: e.name, cam: camJSON(e.camera, 800, 800) }))));
+  } else if (cmd === 'busy') {
+    // busy <records.bin> <n> <W> <H> <uniforms.bin>: the native handle refuses calls while a renderAsync frame is in flight,
+    // and destroy() during the frame is deferred to its completion
+    const rec = fs.readFileSync(process.argv[3]);
+    const n = parseInt(process.argv[4], 10), W = parseInt(process.argv[5], 10), H = parseInt(process.argv[6], 10);
+    const ub = fs.readFileSync(process.argv[7]);
+    const u = new Float32Array(ub.buffer.slice(ub.byteOffset, ub.byteOffset + 160));
+    const nat = g.loadNative();
+    const h = nat.create({ width: W, height: H, tileSize: 16, device: 0 });
+    nat.uploadSplats(h, rec.buffer.slice(rec.byteOffset, rec.byteOffset + rec.byteLength), n);
+    let badN = false;
+    try { nat.uploadSplats(h, rec.buffer, -1); } catch (e) { badN = true; }
+    const p = nat.renderAsync(h, u);
+    let refused = 0;
+    try { nat.renderSync(h, u); } catch (e) { refused += /in flight/.test(String(e)) ? 1 : 0; }
+    try { nat.stats(h); } catch (e) { refused += /in flight/.test(String(e)) ? 1 : 0; }
+    try { nat.renderAsync(h, u); } catch (e) { refused += /in flight/.test(String(e)) ? 1 : 0; }
+    nat.destroy(h); // deferred: the worker still owns the context
+    await p;
+    let gone = false;
+    try { nat.stats(h); } catch (e) { gone = /destroyed/.test(String(e)); }
+    console.log(JSON.stringify({ refused, gone, badN }));
   } else {
     throw new Error('unknown command ' + cmd);
   }

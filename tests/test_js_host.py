@@ -142,3 +142,49 @@ def test_renderer_shares_splats(tmp_path):
     u.tofile(ub)
     info = _node("shared", rec, n, W, H, ts, ub)
     assert info["same"] and info["bytes"] == W * H * 4
+
+
+def test_write_ppm_presentation_sink(tmp_path):
+    """SURVEY 8f-4: js/index.js::writePPM -- binary P6, rgb of every pixel in row-major order, alpha dropped."""
+    W, H = 37, 11
+    out = tmp_path / "f.ppm"
+    _node("ppm", out, W, H)
+    raw = out.read_bytes()
+    head = b"P6\n%d %d\n255\n" % (W, H)
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    i = np.arange(W * H)
+    want = np.stack([i & 255, (i >> 3) & 255, (7 * i) & 255], axis=1).astype(np.uint8)
+    np.testing.assert_array_equal(np.frombuffer(raw[len(head):], dtype=np.uint8).reshape(-1, 3), want)
+
+
+def test_load_camera_file_matches_python_mirror(tmp_path):
+    """camera.ts:323-340,344-400: a 3DGS cameras.json -> list of (img_name, Camera); checked against gsplat.camera.Camera.from_json."""
+    from gsplat.camera import Camera
+    cams = []
+    for k, th in enumerate((0.0, 0.7, -1.9)):
+        c, s_ = float(np.cos(th)), float(np.sin(th))
+        cams.append({"id": k, "img_name": "img_%03d" % k, "width": 1957, "height": 1091, "fx": 1100.0 + k, "fy": 1090.0 - k,
+                     "position": [0.5 * k, -1.0, 2.0 + k], "rotation": [[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]]})
+    path = tmp_path / "cameras.json"
+    path.write_text(json.dumps(cams))
+    js = _node("camfile", path)
+    assert [e["name"] for e in js] == [c["img_name"] for c in cams]
+    for e, raw in zip(js, cams):
+        ref = Camera.from_json(raw)
+        np.testing.assert_allclose(e["cam"]["uniforms"], ref.uniforms(800, 800), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(e["cam"]["view"], ref.viewMatrix, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_native_handle_refuses_calls_while_a_frame_is_in_flight(tmp_path):
+    """gs_ctx is not re-entrant: while renderAsync's worker owns it every other call on the handle throws, destroy() is deferred
+    to the frame's completion (no use-after-free), and a negative splat count is rejected."""
+    from gsplat import synth
+    n, W, H = 200000, 1280, 720
+    s = scene(n)
+    u = synth.orbit_camera(2, W, H).uniforms(W, H)
+    rec, ub = str(tmp_path / "rec.bin"), str(tmp_path / "u.bin")
+    s.tofile(rec)
+    u.tofile(ub)
+    info = _node("busy", rec, n, W, H, ub)
+    assert info["refused"] == 3 and info["gone"] and info["badN"]
