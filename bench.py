@@ -116,38 +116,19 @@ def cpu_baseline(host_scene, n_full, W, H, ts, uniforms, max_n):
     return res, (out if n == n_full else None)
 
 
-def pipelined_pass(gsplat, owner, W, H, ts, device, uniforms, args):
-    """K frames in flight: K-1 more contexts borrow the owner's splats (gs_share_splats) and the same K steps are rendered
-    round-robin, a context being waited for only when its buffers are needed again.  Reported beside `value` (which is the
-    reference's discipline, one frame in flight): the blend of frame k overlaps the binning and sort of frame k+1."""
-    K = args.frames_in_flight
-    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
-    pg.numGaussians, pg.gaussiansBuffer = owner.numGaussians, None
-    rs = [owner] + [gsplat.Renderer(gsplat.Canvas(W, H), None, device, pg, ts, share_with=owner, flags=owner.flags & 1) for _ in range(K - 1)]
-    for r in rs[1:]:
-        if args.tile_cull >= 0:
-            r.set_option(7, args.tile_cull)  # GS_OPT_TILE_CULL
-        if args.emit_order >= 0:
-            r.set_option(_OPT_EMIT_ORDER, args.emit_order)
-        if args.blend_ablation:
-            r.set_option(_OPT_BLEND_ABLATION, args.blend_ablation)
-    for k in range(args.warmup):
-        rs[k % K].render_uniforms(uniforms[k % 64])
-    for r in rs:
-        r.wait()
+def flight_pass(r, _abi, uniforms, args, k):
+    """The same K steps with the context limited to k frames in flight (GS_OPT_FRAMES_IN_FLIGHT), outside the timed region."""
+    r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, k)
+    for i in range(args.warmup):
+        r.render_uniforms(uniforms[i % 64])
+    r.wait()
+    r.set_option(_abi.GS_OPT_RESET_TIMING, 0)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        r = rs[k % K]
-        if k >= K:
-            r.wait()
-        r.render_uniforms(uniforms[(args.warmup + k) % 64])
-    for r in rs:
-        r.wait()
+    for i in range(args.steps):
+        r.render_uniforms(uniforms[(args.warmup + i) % 64])
+    r.wait()
     dt = time.perf_counter() - t0
-    for r in rs[1:]:
-        r.destroy()
-    return {"frames_in_flight": K, "value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
-            "note": "same frames, %d contexts sharing the resident splats rendered round-robin on their own streams" % K}
+    return {"frames_in_flight": k, "value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps}, r.stats()
 
 
 _OPT_EMIT_ORDER, _OPT_BLEND_ABLATION = 4, 1  # gs_abi.h GS_OPT_EMIT_ORDER / GS_OPT_BLEND_ABLATION
@@ -248,9 +229,10 @@ def main():
                     help="N>1: all-gather on a side stream, overlapped with the next frame (multigpu.OverlappedExchange; correct "
                          "under gloo rehearsal but its RCCL timing could not be measured on a one-GPU box, so it is opt-in)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="N=1 only: after the timed region, a second pass with this many frames in flight (contexts sharing the "
-                         "splats, gs_share_splats) is reported as `pipelined`; 0 or 1 skips it.  `value` is always one frame in flight")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="GS_OPT_FRAMES_IN_FLIGHT for the timed region (0 = the library's default: 2 for a whole-canvas context, 1 for a "
+                         "slab); at N=1 the same steps are repeated outside the timed region with the other setting (1 <-> 2) and "
+                         "reported as `other_flight`")
     ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
                     help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
     ap.add_argument("--lib", default="", help="A/B only: another build of libgsplat_hip.so (sets $GSPLAT_LIB)")
@@ -318,6 +300,8 @@ def main():
     torch.cuda.empty_cache()
     if args.tile_cull >= 0:
         r.set_option(_abi.GS_OPT_TILE_CULL, args.tile_cull)
+    if args.frames_in_flight > 0 and world == 1:
+        r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
     if args.grid:
         r.set_option(_abi.GS_OPT_PERSISTENT_GRID, args.grid)
     if args.emit_order >= 0:
@@ -415,7 +399,9 @@ def main():
             "metric": "frames/sec", "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "ply" if args.ply else "synthetic",
-            "frames_in_flight": 1,  # `value`: every frame is enqueued on one stream after the previous one (Renderer.animate's discipline)
+            # frames are enqueued back to back (no host wait inside the timed region, one gs_wait at its end); the context keeps
+            # this many of them in flight (GS_OPT_FRAMES_IN_FLIGHT: a shadow context with its own stream and per-frame arrays)
+            "frames_in_flight": st["frames_in_flight"],
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
                        "parallelism": ("tile-column slabs x%d + all-gather%s" % (world, " overlapped with the next frame" if ovl is not None else ""))
                        if world > 1 else "single GPU",
@@ -426,7 +412,18 @@ def main():
         }
         if verified is not None:
             line["slab_frame_equals_single_gpu_frame"] = verified
-        if not args.no_timing and st["frames_timed"]:
+        stq, stage_source = st, "the timed region"
+        if world == 1 and st["frames_in_flight"] > 1 and not args.no_timing:
+            # the timed region kept two frames in flight: the kernels of consecutive frames overlap there and stretch each other, so
+            # a stage's hipEvent bracket is not a kernel duration any more.  The same steps are run once more, outside the timed
+            # region, strictly one frame after the other: its per-stage times (and the frames/s of that discipline) are what
+            # `stages` and `roofline` are computed from; the overlapped brackets are kept as `stages_overlapped_us`.
+            line["stages_overlapped_us"] = {k_: round(v, 2) for k_, v in st["stage_us_mean"].items()}
+            line["one_frame_in_flight"], stq = flight_pass(r, _abi, uniforms, args, 1)
+            r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, st["frames_in_flight"])
+            stage_source = "the same steps strictly one frame after the other (one_frame_in_flight), outside the timed region"
+        if not args.no_timing and stq["frames_timed"]:
+            st_main, st = st, stq
             ab = algorithmic_bytes(st, W, H, T)
             stages = {}
             for name, us in st["stage_us_mean"].items():
@@ -440,7 +437,7 @@ def main():
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": tdetail,
                                 "alg_bytes_per_launch": int(ab[dom]),
-                                "launch_us": round(dus, 2), "frames_timed": st["frames_timed"],
+                                "launch_us": round(dus, 2), "frames_timed": st["frames_timed"], "measured_in": stage_source,
                                 "rank0_slab_only": world > 1}
             bus = st["stage_us_mean"]["blend"]
             if bus > 0:
@@ -456,8 +453,7 @@ def main():
                     stages[name]["moved_GBps"] = round(mb[name] / (st["stage_us_mean"][name] * 1e-6) / 1e9, 1) if st["stage_us_mean"][name] > 0 else 0.0
             line["stages"] = stages
             line["frame_us_device"] = round(st["frame_us_mean"], 2)
-        if world == 1 and args.frames_in_flight > 1:
-            line["pipelined"] = pipelined_pass(gsplat, r, W, H, ts, local_rank, uniforms, args)
+            st = st_main
         line["capacity"] = {"entries": st["capacity"], "max_intersections_seen": st["max_intersections_seen"],
                             "truncated_frames": st["truncated_frames"]}
         if st["truncated_frames"] or trouble:

@@ -78,6 +78,17 @@ struct gs_ctx {
     int emit_order = 2;                       // GS_OPT_EMIT_ORDER: 0 depth-bucket order, 1 gaussian-index order (reference), 2 auto
     bool index_order = true;                  // what the frame being enqueued uses
     uint32_t debug_view = 0;                  // GS_OPT_DEBUG_VIEW
+    // Frames in flight (GS_OPT_FRAMES_IN_FLIGHT): when gs_render is called while this context's previous frame is still on the
+    // device, the frame goes to a SHADOW context (own stream and per-frame arrays, this context's resident splats), created on
+    // first need; gs_render then alternates between them, so one frame's blend (instruction-issue bound) overlaps the next
+    // frame's projection / binning / sort (memory and latency bound).  gs_wait waits for all of them; read-backs, taps and
+    // statistics refer to the context that rendered the LAST frame.
+    uint32_t fif = 1;                         // allowed frames in flight (1 = none of the above)
+    std::vector<gs_ctx*> shadows;
+    bool is_shadow = false;
+    gs_ctx* last = nullptr;                   // who rendered the last frame (this or a shadow); nullptr = this
+    uint32_t rr = 0;                          // next slot of the ring {this, shadows...}
+    uint64_t cap_hint = 0;                    // largest capacity any member has grown to
     bool tile_cull = true;                    // GS_OPT_TILE_CULL: tight (opacity-aware) binning in gs_render / gs_render_to
     bool last_tight = false;                  // the last frame used it
     bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
@@ -250,12 +261,15 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
             for (auto& e : row) HIP_TRY(hipEventCreate(&e));
         c->have_events = true;
     }
+    c->fif = (c->own_stream && f.full) ? 2u : 1u; // a caller-supplied stream or a slab orders its work with the caller's: one frame
     *out = c;
     return GS_OK;
 }
 
 GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     if (!c) return GS_OK;
+    for (gs_ctx* s : c->shadows) gs_destroy(s);
+    c->shadows.clear();
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_kv(c);
@@ -273,6 +287,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     return GS_OK;
 }
 
+static int32_t wait_one(gs_ctx* c);
 GS_EXPORT int32_t gs_wait(gs_ctx* c);
 // Frees the previous scene and per-gaussian work arrays, allocates the work arrays for n gaussians.
 static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity = 0) {
@@ -320,12 +335,23 @@ static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     return GS_OK;
 }
 
+// a new scene: the shadows of the ring are dropped (they hold arrays sized for the old one and borrow its planes); the next
+// frame that finds its predecessor in flight opens a new one
+static int32_t drop_shadows(gs_ctx* c) {
+    for (gs_ctx* s : c->shadows) gs_destroy(s);
+    c->shadows.clear();
+    c->last = c;
+    c->rr = 0;
+    c->cap_hint = 0;
+    return GS_OK;
+}
 GS_EXPORT int32_t gs_share_splats(gs_ctx* c, gs_ctx* owner) {
     if (!c || !owner || c == owner) return fail(GS_ERR_INVALID_ARGUMENT, "gs_share_splats: needs two distinct contexts");
     if (c->cfg.device != owner->cfg.device) return fail(GS_ERR_INVALID_ARGUMENT, "gs_share_splats: contexts are on different devices");
+    if (!c->is_shadow) drop_shadows(c);
     if (!owner->scene_mem) return fail(GS_ERR_NO_SCENE, "gs_share_splats: the owner holds no splats");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+    if (c->pending) { int32_t rc = wait_one(c); if (rc != GS_OK) return rc; }
     // start from the capacity the owner has already grown to: a borrower exists to keep several frames in flight, and a
     // frame that overflows while others are queued behind it cannot be re-rendered (GS_ERR_TRUNCATED)
     int32_t rc = alloc_per_gaussian(c, owner->n, c->cfg.max_intersections ? 0 : owner->capacity);
@@ -341,6 +367,7 @@ GS_EXPORT int32_t gs_upload_splats_device(gs_ctx* c, const void* d_aos, uint64_t
     if (!c || (!d_aos && n)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats_device: null argument");
     if (n >= (1ull << 31)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats: too many gaussians");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    drop_shadows(c);
     return upload_common(c, d_aos, n);
 }
 
@@ -348,6 +375,7 @@ GS_EXPORT int32_t gs_upload_splats(gs_ctx* c, const void* aos, uint64_t n) {
     if (!c || (!aos && n)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats: null argument");
     if (n >= (1ull << 31)) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_splats: too many gaussians");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    drop_shadows(c);
     void* d = nullptr;
     const size_t bytes = (size_t)n * GS_SPLAT_RECORD_BYTES;
     HIP_TRY(hipMalloc(&d, std::max<size_t>(bytes, 256)));
@@ -502,14 +530,8 @@ static int32_t render_common(gs_ctx* c, const void* uniforms, bool debug, void* 
     memcpy(&u, uniforms, sizeof(u));
     return enqueue_frame(c, u, debug, ext);
 }
-GS_EXPORT int32_t gs_render(gs_ctx* c, const void* uniforms) { return render_common(c, uniforms, false, nullptr); }
-GS_EXPORT int32_t gs_render_debug(gs_ctx* c, const void* uniforms) { return render_common(c, uniforms, true, nullptr); }
-GS_EXPORT int32_t gs_render_to(gs_ctx* c, const void* uniforms, void* d_rgba8) {
-    if (!d_rgba8) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render_to: null output");
-    return render_common(c, uniforms, false, d_rgba8);
-}
 
-GS_EXPORT int32_t gs_wait(gs_ctx* c) {
+static int32_t wait_one(gs_ctx* c) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_wait: null ctx");
     HIP_TRY(hipSetDevice(c->cfg.device));
     uint32_t dropped = 0; // frames enqueued before the last one that overflowed: their output was truncated and is gone
@@ -551,6 +573,81 @@ GS_EXPORT int32_t gs_wait(gs_ctx* c) {
     return GS_OK;
 }
 
+static gs_ctx* last_of(gs_ctx* c) { return (c && c->last) ? c->last : c; }
+
+GS_EXPORT int32_t gs_wait(gs_ctx* c) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_wait: null ctx");
+    int32_t first = wait_one(c);
+    char msg[sizeof(g_err)];
+    if (first != GS_OK) memcpy(msg, g_err, sizeof(msg));
+    for (gs_ctx* s : c->shadows) {
+        const int32_t rc = wait_one(s);
+        if (rc != GS_OK && first == GS_OK) { first = rc; memcpy(msg, g_err, sizeof(msg)); }
+    }
+    c->cap_hint = std::max(c->cap_hint, c->capacity);
+    for (gs_ctx* s : c->shadows) c->cap_hint = std::max(c->cap_hint, s->capacity);
+    if (first != GS_OK) memcpy(g_err, msg, sizeof(msg));
+    return first;
+}
+
+static int32_t set_option_one(gs_ctx* c, int32_t key, int64_t value);
+// One more member of the ring: a context with this one's configuration that borrows its splats.
+static int32_t add_shadow(gs_ctx* c) {
+    gs_config cfg = c->cfg;
+    cfg.stream = nullptr;
+    cfg.max_intersections = 0; // starts from the owner's capacity (gs_share_splats)
+    gs_ctx* s = nullptr;
+    int32_t rc = gs_create(&cfg, &s);
+    if (rc != GS_OK) return rc;
+    s->fif = 1;
+    s->is_shadow = true;
+    rc = gs_share_splats(s, c);
+    if (rc != GS_OK) { gs_destroy(s); return rc; }
+    s->emit_order = c->emit_order; s->tile_cull = c->tile_cull; s->unfused = c->unfused; s->debug_view = c->debug_view;
+    s->blend_ablation = c->blend_ablation; s->old_gsort = c->old_gsort; s->grid_persist = c->grid_persist; s->timed_from = 0;
+    c->shadows.push_back(s);
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_render(gs_ctx* c, const void* uniforms) {
+    if (!c || !uniforms) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render: null argument");
+    gs_ctx* t = c;
+    if (c->fif > 1 && c->scene_mem) {
+        // a second frame while the first is still in flight: open the next slot of the ring (once), then take turns
+        if (c->pending && c->shadows.size() + 1 < c->fif) {
+            int32_t rc = add_shadow(c);
+            if (rc != GS_OK) return rc;
+            c->rr = (uint32_t)c->shadows.size(); // the new slot takes this frame
+        }
+        if (!c->shadows.empty()) {
+            const uint32_t slot = c->rr++ % (uint32_t)(c->shadows.size() + 1);
+            t = slot ? c->shadows[slot - 1] : c;
+        }
+        if (t->capacity < c->cap_hint) { // another member has met a bigger frame: grow before, not after, truncating one
+            HIP_TRY(hipSetDevice(t->cfg.device));
+            if (t->pending) { int32_t rc = wait_one(t); if (rc != GS_OK && rc != GS_ERR_TRUNCATED) return rc; }
+            hipFree(t->keysU); hipFree(t->valsU); t->keysU = t->valsU = nullptr;
+            int32_t rc = alloc_kv(t, c->cap_hint);
+            if (rc != GS_OK) return rc;
+            t->have_frame = false;
+        }
+    }
+    const int32_t rc = render_common(t, uniforms, false, nullptr);
+    if (rc == GS_OK) c->last = t;
+    return rc;
+}
+GS_EXPORT int32_t gs_render_debug(gs_ctx* c, const void* uniforms) {
+    const int32_t rc = render_common(c, uniforms, true, nullptr);
+    if (rc == GS_OK && c) c->last = c;
+    return rc;
+}
+GS_EXPORT int32_t gs_render_to(gs_ctx* c, const void* uniforms, void* d_rgba8) {
+    if (!d_rgba8) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render_to: null output");
+    const int32_t rc = render_common(c, uniforms, false, d_rgba8);
+    if (rc == GS_OK && c) c->last = c;
+    return rc;
+}
+
 GS_EXPORT int32_t gs_slab_width(gs_ctx* c, uint32_t* px_begin, uint32_t* px_width) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_slab_width: null ctx");
     if (px_begin) *px_begin = c->frame.px0;
@@ -575,7 +672,7 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
         *bytes = I * 4;
         if (!c->last_keys16) { *ptr = c->keysS; return GS_OK; }
         if (!c->keysG_valid) { // the frame was sorted on 16-bit tile ids: rebuild tile*1000 + bucket once
-            if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+            if (c->pending) { int32_t rc = wait_one(c); if (rc != GS_OK) return rc; }
             if (!c->keysG) HIP_TRY(hipMalloc((void**)&c->keysG, (size_t)c->capacity * 4));
             gs_launch_rebuild_keys((const uint16_t*)c->keysS, c->valsS, c->counts, (uint32_t)I, c->n, c->last_tight ? GS_ID_MASK : 0xFFFFFFFFu, c->keysG, c->stream);
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -599,8 +696,9 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
 
 GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t size, uint64_t* written) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: null ctx");
+    c = last_of(c);
     if (!c->have_frame) return fail(GS_ERR_NO_FRAME, "gs_read_buffer: no frame rendered");
-    if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+    if (c->pending) { int32_t rc = wait_one(c); if (rc != GS_OK) return rc; }
     HIP_TRY(hipSetDevice(c->cfg.device));
     void* p = nullptr;
     uint64_t bytes = 0;
@@ -653,27 +751,32 @@ GS_EXPORT int32_t gs_read_rgba8(gs_ctx* c, void* dst, uint64_t size) {
 
 GS_EXPORT int32_t gs_device_ptr(gs_ctx* c, int32_t which, void** d_ptr) {
     if (!c || !d_ptr) return fail(GS_ERR_INVALID_ARGUMENT, "gs_device_ptr: null argument");
+    c = last_of(c);
     uint64_t bytes = 0;
     if (which == GS_BUF_RGBA8) { *d_ptr = c->rgba8; return GS_OK; }
     if (!c->have_frame) return fail(GS_ERR_NO_FRAME, "gs_device_ptr: no frame rendered");
     return tap(c, which, d_ptr, &bytes);
 }
 
-GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
-    if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_get_stats: null argument");
-    if (c->pending) { int32_t rc = gs_wait(c); if (rc != GS_OK) return rc; }
+GS_EXPORT int32_t gs_get_stats(gs_ctx* root, gs_stats* out) {
+    if (!root || !out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_get_stats: null argument");
+    gs_ctx* c = last_of(root); // everything below describes the context that rendered the last frame ...
+    if (c->pending) { int32_t rc = wait_one(c); if (rc != GS_OK) return rc; }
     memset(out, 0, sizeof(*out));
     out->num_gaussians = c->n;
     out->num_tiles = c->T;
     out->sort_passes = c->last_passes ? c->last_passes : c->passes;
-    out->frames = c->frames;
+    out->frames = root->frames; // ... except the counters that are sums over the ring
+    for (gs_ctx* s : root->shadows) out->frames += s->frames;
     out->depth_ordered = (c->have_frame && !c->last_by_index) ? 1u : 0u;
     if (c->have_frame) {
         out->num_visible = c->h_ctl->num_visible;
         out->num_intersections = c->h_ctl->num_intersections;
         out->capacity = c->capacity;
         out->max_intersections_seen = std::max<uint64_t>(c->max_I_seen, c->h_ctl->num_intersections);
-        out->truncated_frames = c->truncated_frames;
+        out->truncated_frames = root->truncated_frames;
+        for (gs_ctx* s : root->shadows) out->truncated_frames += s->truncated_frames;
+        out->frames_in_flight = (uint32_t)root->shadows.size() + 1u;
         out->tight_binning = c->last_tight ? 1u : 0u;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
         if (c->blend_walkers >= 4) { // 8x8-block walkers (4 per 16-tile, 16 per 32-tile): sum over tiles of the deepest walker
@@ -720,6 +823,25 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* c, gs_stats* out) {
 
 GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: null ctx");
+    if (key == GS_OPT_FRAMES_IN_FLIGHT) {
+        if (value < 1 || value > 4) return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: frames in flight must be 1..4");
+        if (!c->own_stream || !c->frame.full) value = 1; // a caller-supplied stream / a slab: see gs_create
+        int32_t rc = gs_wait(c);
+        if (rc != GS_OK && rc != GS_ERR_TRUNCATED) return rc;
+        while (c->shadows.size() + 1 > (size_t)value) { // the last frame may live in a shadow that goes away: taps need a new frame
+            if (c->last == c->shadows.back()) { c->last = c; }
+            gs_destroy(c->shadows.back());
+            c->shadows.pop_back();
+        }
+        c->fif = (uint32_t)value;
+        c->rr = 0;
+        return GS_OK;
+    }
+    int32_t rc = set_option_one(c, key, value);
+    for (gs_ctx* s : c->shadows) if (rc == GS_OK) rc = set_option_one(s, key, value);
+    return rc;
+}
+static int32_t set_option_one(gs_ctx* c, int32_t key, int64_t value) {
     switch (key) {
     case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value & 0x3FFFFu; c->old_gsort = ((uint32_t)value & 0x40000u) != 0; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;

@@ -144,7 +144,7 @@ class Renderer:
         check(self._L.gs_get_stats(self._ctx, ctypes.byref(s)))
         d = {k: getattr(s, k) for k in ("num_gaussians", "num_visible", "num_intersections", "num_processed", "num_tiles",
                                         "sort_passes", "frames", "frame_us", "frame_us_mean", "frames_timed", "num_evaluated", "depth_ordered",
-                                        "capacity", "max_intersections_seen", "truncated_frames", "tight_binning")}
+                                        "capacity", "max_intersections_seen", "truncated_frames", "tight_binning", "frames_in_flight")}
         d["stage_us"] = {n: s.stage_us[i] for i, n in enumerate(_abi.GS_STAGE_NAMES)}
         d["stage_us_mean"] = {n: s.stage_us_mean[i] for i, n in enumerate(_abi.GS_STAGE_NAMES)}
         self.numIntersections = d["num_intersections"]
@@ -179,6 +179,8 @@ class PipelinedRenderer:
         first = Renderer(canvas, interactiveCamera, device, gaussians, tileSize, **kw)
         self.renderers = [first] + [Renderer(canvas, interactiveCamera, device, gaussians, tileSize, share_with=first, **kw)
                                     for _ in range(frames_in_flight - 1)]
+        for r in self.renderers:  # this class IS the explicit form of the library's own ring: its members render one frame at a time
+            r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)
         self.canvas, self.interactiveCamera = canvas, interactiveCamera
         self._next = 0
         self._busy = [False] * frames_in_flight

@@ -257,6 +257,7 @@ def test_truncated_frames_are_reported(oracle):
     need = max(oracle.render(s, u, W, H, 16)["num_intersections"] for u in us)
     r = make_renderer(s, W, H, 16, max_intersections=4096, flags=_abi.GS_FLAG_EXACT_BLEND)
     r.set_option(_abi.GS_OPT_TILE_CULL, 0)
+    r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)  # all three frames on the one context
     assert need > 4096
     for u in us:
         r.render_uniforms(u)
@@ -272,3 +273,44 @@ def test_truncated_frames_are_reported(oracle):
     r.wait()  # no error this time
     np.testing.assert_array_equal(r.read_rgba8(), ref["rgba8"])
     r.destroy()
+
+
+def test_frames_in_flight_ring(oracle):
+    """GS_OPT_FRAMES_IN_FLIGHT (default 2): frames enqueued without waiting alternate between the context and a shadow that
+    borrows its splats; every frame is what a strictly sequential context renders, gs_wait covers the whole ring, taps and
+    statistics describe the last frame; a frame that overflows in one member grows the others before they meet it."""
+    from conftest import scene
+    from gsplat import _abi
+    n, W, H = 60000, 640, 360
+    s = scene(n)
+    us = [orbit_uniforms(W, H, step=k) for k in range(9)]
+    seq = make_renderer(s, W, H, 16)
+    seq.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)
+    want = []
+    for u in us:
+        seq.render_uniforms(u); seq.wait()
+        want.append(seq.read_rgba8())
+    assert seq.stats()["frames_in_flight"] == 1
+    r = make_renderer(s, W, H, 16, max_intersections=8192)  # far too small: both members have to grow
+    r.render_uniforms(us[0]); r.wait()
+    np.testing.assert_array_equal(r.read_rgba8(), want[0])
+    assert r.stats()["frames_in_flight"] == 1  # nothing was ever in flight behind a frame
+    for k in (1, 2):  # two frames back to back: the second opens the shadow
+        r.render_uniforms(us[k])
+    r.wait()
+    st = r.stats()
+    assert st["frames_in_flight"] == 2 and st["frames"] == 3
+    np.testing.assert_array_equal(r.read_rgba8(), want[2])
+    ref = oracle.render(s, us[2], W, H, 16)
+    check_product_lists(r, ref, oracle, W, H, 16)  # the taps are the last frame's, wherever it was rendered
+    for k in range(3, 9, 2):  # pairs of frames in flight, one per member; the read-back is the pair's second frame
+        r.render_uniforms(us[k])
+        r.render_uniforms(us[k + 1])
+        r.wait()
+        np.testing.assert_array_equal(r.read_rgba8(), want[k + 1])
+    assert r.stats()["truncated_frames"] == 0
+    r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)
+    assert r.stats()["frames_in_flight"] == 1
+    r.render_uniforms(us[5]); r.wait()
+    np.testing.assert_array_equal(r.read_rgba8(), want[5])
+    r.destroy(); seq.destroy()

@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 i=0
 for a in "$@"; do
   i=$((i+1))
-  timeout -k 10 300 python bench.py --no-cpu --frames-in-flight 0 --no-verify --steps 100 --warmup 10 $a > $OUT/v$i.json 2> $OUT/v$i.err || echo "variant $i failed"
+  timeout -k 10 300 python bench.py --no-cpu --no-verify --steps 100 --warmup 10 $a > $OUT/v$i.json 2> $OUT/v$i.err || echo "variant $i failed"
   python - <<PY
 import json
 try:

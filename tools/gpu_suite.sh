@@ -15,5 +15,5 @@ d = json.load(open("$OUT/bench.json"))
 print({k: d.get(k) for k in ("value", "ms_per_step", "frame_verified", "frame_verified_detail", "exact_blend", "capacity", "valid")})
 print(d.get("cpu_baseline"))
 print({k: v["us"] for k, v in d.get("stages", {}).items()}, d.get("config"))
-print(d.get("pipelined"))
+print(d.get("one_frame_in_flight"), "frames_in_flight", d.get("frames_in_flight"), d.get("roofline"))
 PY

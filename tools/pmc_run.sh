@@ -10,7 +10,7 @@ i=0
 for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
             "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pass$i" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu --no-timing --frames-in-flight 0 "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pass$i" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu --no-timing --frames-in-flight 1 --no-verify "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
