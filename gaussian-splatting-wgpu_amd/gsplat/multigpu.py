@@ -57,8 +57,15 @@ class SlabExchange:
         if self.world == 1:
             gathered.copy_(send)
         elif dist.get_backend() == "gloo":
+            # rehearsal path (CPU tests, several ranks on one GPU): gloo stages device tensors through the host on streams of its
+            # own, so the frame has to be complete before it reads `send` and its copies back into `gathered` have to be complete
+            # before the assembly reads them (with 4 ranks on one GPU the unsynchronised form assembled stale slabs)
+            if send.is_cuda:
+                self.torch.cuda.synchronize(send.device)
             parts = list(gathered.view(self.world, self.stride).unbind(0))
             dist.all_gather(parts, send)
+            if send.is_cuda:
+                self.torch.cuda.synchronize(send.device)
         else:
             dist.all_gather_into_tensor(gathered, send)
 

@@ -12,9 +12,12 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pass$i" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu --no-timing --frames-in-flight 1 --no-verify "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
+python3 - "$OUT" "$REPO" "$@" <<'PY'
+import csv, glob, sys, collections, os
+out, repo, bargs = sys.argv[1], sys.argv[2], sys.argv[3:]
+sys.path.insert(0, repo)
+import bench
+cfgname = bargs[bargs.index("--config") + 1] if "--config" in bargs else "B"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
@@ -29,7 +32,8 @@ with open(out + "/pmc_summary.csv", "w") as w:
         n = max(len(v) for v in agg[k].values())
         w.write(k.replace(",", ";") + "," + str(n) + "," + ",".join("%.6g" % (sum(agg[k][c]) / len(agg[k][c])) if c in agg[k] else "" for c in names) + "\n")
 import json
-js = {"note": "mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them (tools/pmc_run.sh, 4 separate --pmc passes)",
+js = {"workload": bench.CONFIGS[cfgname]["name"], "bench_args": " ".join(bargs),
+      "note": "mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them (tools/pmc_run.sh, 4 separate --pmc passes)",
       "kernels": {k.replace("void ", "").replace("<false>", "").replace("<true>", "_exact"): {c: sum(v) / len(v) for c, v in agg[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")} for k in agg}}
 json.dump(js, open(out + "/pmc.json", "w"), indent=1)
 print(open(out + "/pmc_summary.csv").read())
