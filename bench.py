@@ -54,17 +54,21 @@ def algorithmic_bytes(st, W, H, T):
 
 
 def moved_bytes(st, W, H, T, tile16):
-    """What THIS build's kernels read + write per frame (beside SURVEY 8(d)'s reference-equivalent figures): the depth-ordered
-    pipeline keeps 16-bit tile ids as instance sort words (12 instead of 16 bytes per pair and sweep, no histogram pass),
-    emission writes 6 bytes per instance, ranges read 2."""
-    N, Nv, I, Ip, p = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"]
+    """What THIS build's kernels read + write per frame (beside SURVEY 8(d)'s reference-equivalent figures), depth-ordered
+    pipeline on 16-bit tile ids: projection reads the 12-byte position and, of a visible gaussian, its whole 256-byte record,
+    writes the 64-byte GaussianData and the count word; the scan stage reads the N count words, writes the compacted (bucket,
+    id, word) of the visible ones and counting-sorts them (hist 4, scatter 8 + 12, bucket table ~8 MB); the emission reads
+    48 bytes of GaussianData + 12 per visible gaussian and writes 6 bytes per instance; each sweep moves 12 bytes per pair;
+    ranges read 2 bytes per instance; the blend reads 4 bytes per staged entry per walker that stages it (<= 4) and 40 bytes
+    of GaussianData per (walker, entry) it evaluates, and writes 4 bytes per pixel."""
+    N, Nv, I, Ip, p, Ev = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"], st["num_evaluated"]
     if st.get("depth_ordered") and tile16:
-        return {"preprocess": 12 * (N - Nv) + 268 * Nv + 4 * N + 64 * Nv, "scan": 8 * N + (8 + 2 * 16 + 4 + 12) * Nv,
-                "emit": 40 * Nv + 6 * I, "sort": 12 * p * I, "ranges": 2 * I + 4 * T, "blend": 4 * I + 48 * Ip + 4 * W * H}
+        return {"preprocess": 12 * N + 256 * Nv + 4 * N + 64 * Nv, "scan": 4 * N + 12 * Nv + (4 + 8 + 12) * Nv + 8 * (1 << 20),
+                "emit": 60 * Nv + 6 * I, "sort": 12 * p * I, "ranges": 2 * I + 4 * T, "blend": 16 * Ip + 40 * Ev + 4 * W * H}
     return None
 
 
-STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_balanced_kernel", "gs_emit_kernel"],
+STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_tight_kernel", "gs_emit_balanced_kernel", "gs_emit_kernel"],
                  "sort": ["gs_sort_sweep_kernel<unsigned short>", "gs_sort_sweep_kernel<unsigned int>", "gs_sort_sweep_kernel"],
                  "ranges": ["gs_ranges16_kernel", "gs_ranges_kernel"],
                  "blend": ["gs_blend_quad_kernel", "gs_blend_wave_kernel", "gs_blend_kernel"]}
@@ -85,7 +89,7 @@ def pmc_traffic(stage, workload):
     if js.get("workload") != workload:
         return None, None
     for k in STAGE_KERNELS[stage]:
-        c = js["kernels"].get(k)
+        c = next((v for name, v in js["kernels"].items() if name.startswith(k)), None)  # template arguments follow the name
         if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, {"kernel": k, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
                                                                        "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count for 16 B/lane reads)",
