@@ -12,7 +12,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -ffp-contract=off: one IEEE rounding per written operation (canonical semantics);
 # fused operations are spelled __builtin_fmaf where they are wanted.
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+# -fno-slp-vectorize: the SLP vectoriser turns adjacent scalar f32 multiplies/adds into v_pk_mul_f32 / v_pk_fma_f32, which issue
+# slower than the two scalar instructions they replace on gfx950 and need register pairs (extra moves, waits right behind
+# loads): projection 282 -> 243 us, blend 738 -> 712 us with the flag (profiles/README.md).
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_gsort.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
 
