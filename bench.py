@@ -234,9 +234,9 @@ def main():
                          "under gloo rehearsal but its RCCL timing could not be measured on a one-GPU box, so it is opt-in)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="GS_OPT_FRAMES_IN_FLIGHT for the timed region (0 = the library's default: 2 for a whole-canvas context, 1 for a "
-                         "slab); at N=1 the same steps are repeated outside the timed region with the other setting (1 <-> 2) and "
-                         "reported as `other_flight`")
+                    help="GS_OPT_FRAMES_IN_FLIGHT for the timed region (0 = the library's default: 3 for a whole-canvas context, 1 for a "
+                         "slab); at N=1 the same steps are repeated outside the timed region strictly one frame after the other "
+                         "(`one_frame_in_flight`), which is also where `stages` and `roofline` are measured")
     ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
                     help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
     ap.add_argument("--lib", default="", help="A/B only: another build of libgsplat_hip.so (sets $GSPLAT_LIB)")

@@ -107,18 +107,31 @@ __device__ __forceinline__ float gs_exp(float x) {
 // ---- wave64 helpers -------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v += t;
-    }
+// Scans run on DPP row shifts and row broadcasts (VALU latency, no trip through the LDS crossbar as
+// ds_bpermute would make): shr 1,2,4,8 inside each row of 16, then lane 15 -> row 1 and 3, lane 31 -> rows 2,3.
+// A lane whose source is out of range or masked off reads `old` = the identity.
+#define GS_DPP(v, ctrl, rm) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rm), 0xf, false)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t) {
+    v += GS_DPP(v, 0x111, 0xf);
+    v += GS_DPP(v, 0x112, 0xf);
+    v += GS_DPP(v, 0x114, 0xf);
+    v += GS_DPP(v, 0x118, 0xf);
+    v += GS_DPP(v, 0x142, 0xa);
+    v += GS_DPP(v, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) { // unsigned: the identity is 0
+    uint32_t t;
+    t = GS_DPP(v, 0x111, 0xf); v = (t > v) ? t : v;
+    t = GS_DPP(v, 0x112, 0xf); v = (t > v) ? t : v;
+    t = GS_DPP(v, 0x114, 0xf); v = (t > v) ? t : v;
+    t = GS_DPP(v, 0x118, 0xf); v = (t > v) ? t : v;
+    t = GS_DPP(v, 0x142, 0xa); v = (t > v) ? t : v;
+    t = GS_DPP(v, 0x143, 0xc); v = (t > v) ? t : v;
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0u), 63);
 }
 
 // ---- inter-workgroup words (cdna_hip_programming.md Guideline 16, form R2: the data is the flag) --

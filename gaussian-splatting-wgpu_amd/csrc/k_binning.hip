@@ -36,18 +36,17 @@ __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
     const uint32_t s = a + b;
     return s < a ? 0xFFFFFFFFu : s;
 }
-__device__ __forceinline__ uint32_t wave_incl_scan_sat(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v = sat_add(v, t);
-    }
+__device__ __forceinline__ uint32_t wave_incl_scan_sat(uint32_t v, uint32_t) {
+    v = sat_add(v, GS_DPP(v, 0x111, 0xf));
+    v = sat_add(v, GS_DPP(v, 0x112, 0xf));
+    v = sat_add(v, GS_DPP(v, 0x114, 0xf));
+    v = sat_add(v, GS_DPP(v, 0x118, 0xf));
+    v = sat_add(v, GS_DPP(v, 0x142, 0xa));
+    v = sat_add(v, GS_DPP(v, 0x143, 0xc));
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum_sat(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = sat_add(v, __shfl_xor(v, d, 64));
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_sat(v, 0u), 63);
 }
 
 // counts[] words are packed by the preprocess: tile count in the low 22 bits, depth bucket (the low part of
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
 struct EmitTightWave {
     uint32_t off[64], rp[64], run[64], gid[64], y0b[64], cols[64];
     float4 pA[64], pB[64], pC[64];
-    uint32_t incl[64], slot[64], rowbase[64], tlo[64], first[64], s0[64], s1[64], rgid[64], rbucket[64], amask[64];
+    uint32_t incl[64], slot[64], rowbase[64], tlo[64], first[64], s0[64], s1[64], rgid[64], amask[64], mark[64]; // (5 workgroups of 4 waves + the histogram = 160 KB)
 };
 
 __global__ __launch_bounds__(256, 5) void gs_emit_tight_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
@@ -489,15 +488,12 @@ __global__ __launch_bounds__(256, 5) void gs_emit_tight_kernel(const uint4* __re
                 }
             }
             // slots covered by this group end where its last present member's instances end
-            uint32_t gend = (k < nel) ? off + cnt : 0u;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const uint32_t o = __shfl_xor(gend, d, 64);
-                gend = o > gend ? o : gend;
-            }
+            const uint32_t gend = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max((k < nel) ? off + cnt : 0u), 63);
             const uint32_t stop = gend < S1 ? gend : S1;
             const uint32_t rincl = wave_incl_scan(nrows, lane);
-            const uint32_t R = __shfl(rincl, 63, 64);
+            const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
+            const uint32_t myrp = rincl - nrows;
+            uint32_t jcarry = 0u; // owner (+1) of the row-item just before the batch
             S.off[lane] = off;
             S.rp[lane] = rincl - nrows;
             S.run[lane] = 0u;
@@ -513,12 +509,20 @@ __global__ __launch_bounds__(256, 5) void gs_emit_tight_kernel(const uint4* __re
                 // ---- row-items: lane = (gaussian j of the group, tile row) ----
                 const uint32_t ri = rb + lane;
                 uint32_t len = 0, mainlen = 0, slot0 = 0, j = 0, rowbase = 0, tlo = 0, w0 = 0, w1 = 0, am = 0;
+                // owner of a row-item = the member whose rows [rp, rp + nrows) hold it: every member with rows marks the batch
+                // position of its first one, a running maximum spreads the marks (DPP, no chain of dependent LDS reads)
+                S.mark[lane] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (nrows && myrp >= rb && myrp < rb + 64u) S.mark[myrp - rb] = lane + 1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    uint32_t m = wave_incl_max(S.mark[lane]);
+                    m = m > jcarry ? m : jcarry;
+                    jcarry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+                    j = m ? m - 1u : 0u;
+                }
                 if (ri < R) {
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) { // largest j with rp[j] <= ri (rows-less members share their successor's prefix)
-                        const uint32_t m = j + step;
-                        if (m < 64 && S.rp[m] <= ri) j = m;
-                    }
                     const float4 a = S.pA[j], b = S.pB[j], cc = S.pC[j];
                     TightG g;
                     g.gx = a.x; g.gy = a.y; g.cx = a.z; g.cy = a.w; g.cz = b.x; g.cxz = b.y; g.lim2 = b.z; g.rcx = b.w;
@@ -571,28 +575,35 @@ __global__ __launch_bounds__(256, 5) void gs_emit_tight_kernel(const uint4* __re
                 if (slot0 + len > S1) j1 = S1 > slot0 ? S1 - slot0 : 0u;
                 const uint32_t lenx = j1 > j0 ? j1 - j0 : 0u;
                 const uint32_t xincl = wave_incl_scan(lenx, lane);
-                const uint32_t xtotal = __shfl(xincl, 63, 64);
-                S.incl[lane] = xincl;
+                const uint32_t xtotal = (uint32_t)__builtin_amdgcn_readlane((int)xincl, 63);
+                const uint32_t xex = xincl - lenx;
+                S.incl[lane] = xex;
                 S.slot[lane] = slot0 + j0;
                 S.rowbase[lane] = rowbase;
                 S.tlo[lane] = tlo;
                 S.first[lane] = j0 | (mainlen << 16);
                 S.s0[lane] = w0;
                 S.s1[lane] = w1;
-                S.amask[lane] = am;
+                S.amask[lane] = am | ((ri < R) ? ((S.y0b[j] >> 16) << 4) : 0u); // alias sub-blocks, depth bucket
                 S.rgid[lane] = (ri < R) ? S.gid[j] : 0u; // (through LDS, not a shuffle: the instance loop's last trip is divergent)
-                S.rbucket[lane] = (ri < R) ? (S.y0b[j] >> 16) : 0u;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // ---- instances: lane = one output slot of the batch ----
-                for (uint32_t t = lane; t < xtotal; t += 64) {
-                    uint32_t i = 0; // smallest i with incl[i] > t
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) {
-                        const uint32_t m = i + step;
-                        if (m <= 64 && S.incl[m - 1] <= t) i = m;
-                    }
-                    const uint32_t ex = i ? S.incl[i - 1] : 0u;
+                uint32_t icarry = 0u;
+                for (uint32_t t0 = 0; t0 < xtotal; t0 += 64) {
+                    // owner of an output slot: the row-item whose clipped run [xex, xex + lenx) holds it (marks as above)
+                    S.mark[lane] = 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    if (lenx && xex >= t0 && xex < t0 + 64u) S.mark[xex - t0] = lane + 1u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    uint32_t mm = wave_incl_max(S.mark[lane]);
+                    mm = mm > icarry ? mm : icarry;
+                    icarry = (uint32_t)__builtin_amdgcn_readlane((int)mm, 63);
+                    const uint32_t t = t0 + lane;
+                    if (t >= xtotal) continue;
+                    const uint32_t i = mm - 1u;
+                    const uint32_t ex = S.incl[i];
                     const uint32_t fw = S.first[i];
                     const uint32_t q = (fw & 0xFFFFu) + (t - ex); // instance of the row
                     const uint32_t ml = fw >> 16;
@@ -612,9 +623,9 @@ __global__ __launch_bounds__(256, 5) void gs_emit_tight_kernel(const uint4* __re
                         }
                     } else { // the aliased instance: column ntx of this row = tile (row + 1, 0) (write_tile_ids.wgsl:29)
                         tile_id = S.rowbase[i] + f.ntx;
-                        mask = S.amask[i];
+                        mask = S.amask[i] & 15u;
                     }
-                    const uint32_t og = S.rgid[i], ob = S.rbucket[i];
+                    const uint32_t og = S.rgid[i], ob = S.amask[i] >> 4;
                     if (keys16) reinterpret_cast<uint16_t*>(keys)[dst] = (uint16_t)tile_id;
                     else keys[dst] = tile_id * 1000u + ob;
                     values[dst] = og | (mask << GS_ID_BITS);

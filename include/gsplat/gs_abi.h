@@ -198,11 +198,11 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     blocks it can touch.  GS_BUF_KEYS / VALUES / RANGES / TILE_COUNTS of such a frame describe that
                                     subset.  0: the reference's binning (every tile of the 3-sigma rect, process_gaussians.wgsl:74-86)
                                     as gs_render_debug always uses.                                                              */
-#define GS_OPT_FRAMES_IN_FLIGHT 8 /* 1..4, default 2 for a whole-canvas ctx on its own stream (1 for slabs and caller-supplied streams).
+#define GS_OPT_FRAMES_IN_FLIGHT 8 /* 1..4, default 3 for a whole-canvas ctx on its own stream (1 for slabs and caller-supplied streams).
                                     Renderer.animate awaits every frame (renderer.ts:404-587), so it never has two in flight; a host
                                     that enqueues frame k+1 before waiting for frame k gets it rendered by a shadow of the ctx (own
                                     stream and per-frame arrays, the same resident splats; created on first need), gs_render
-                                    alternating between them: frame k's blend overlaps frame k+1's binning.  Every frame's result
+                                    taking turns between them: frame k's blend overlaps frame k+1's binning.  Every frame's result
                                     is what a single context renders; gs_wait waits for all; read-backs, taps and statistics refer
                                     to the LAST frame.  1 = strictly one frame after the other.                                  */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
