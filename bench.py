@@ -229,14 +229,16 @@ def main():
     ap.add_argument("--cpu-max", type=int, default=10_000_000, help="CPU baseline: render the whole scene on the host unless it has more gaussians than this")
     ap.add_argument("--exact", action="store_true", help="time the bit-exact blend (GS_FLAG_EXACT_BLEND) instead of the default fused one")
     ap.add_argument("--tile-cull", type=int, default=-1, help="GS_OPT_TILE_CULL override (1 = tight binning, default; 0 = the reference's rect binning)")
-    ap.add_argument("--overlap-exchange", action="store_true",
-                    help="N>1: all-gather on a side stream, overlapped with the next frame (multigpu.OverlappedExchange; correct "
-                         "under gloo rehearsal but its RCCL timing could not be measured on a one-GPU box, so it is opt-in)")
+    ap.add_argument("--collective", default="gather", choices=["gather", "all_gather"],
+                    help="N>1: slabs go to the presenting rank only (RCCL send/recv to rank 0, default) or to every rank")
+    ap.add_argument("--even-slabs", action="store_true",
+                    help="N>1: equal tile-column slabs instead of slabs balanced by the instance counts of a calibration pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="GS_OPT_FRAMES_IN_FLIGHT for the timed region (0 = the library's default: 3 for a whole-canvas context, 1 for a "
-                         "slab); at N=1 the same steps are repeated outside the timed region strictly one frame after the other "
-                         "(`one_frame_in_flight`), which is also where `stages` and `roofline` are measured")
+                    help="frames in flight in the timed region (0 = default: 3).  N=1: GS_OPT_FRAMES_IN_FLIGHT of the context; N>1: "
+                         "slab contexts per rank (multigpu.PipelinedSlabs).  The same steps are repeated outside the timed region "
+                         "strictly one frame after the other (`one_frame_in_flight`), which is also where `stages` and `roofline` "
+                         "are measured")
     ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
                     help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
     ap.add_argument("--lib", default="", help="A/B only: another build of libgsplat_hip.so (sets $GSPLAT_LIB)")
@@ -276,8 +278,6 @@ def main():
 
     seed = synth.BASE_SEED + {"A": 0, "B": 1, "C": 2, "E": 4}[args.config]
     from gsplat import multigpu
-    bounds = multigpu.slab_bounds(W, ts, world)  # tile-column slabs (SURVEY 8e)
-    cols = (bounds[rank], bounds[rank + 1])
 
     ply_records = None
     if args.ply:  # a real scene when the box has one (never the case offline)
@@ -287,59 +287,81 @@ def main():
         splats = torch.from_numpy(ply_records).to(dev)
     else:
         splats = synth.bicycle_like_torch(N, seed, dev)  # every rank holds the full replica
-    flags = (0 if args.no_timing else _abi.GS_FLAG_TIMING) | (_abi.GS_FLAG_EXACT_BLEND if args.exact else 0)
-    # N > 1: the frame, the all-gather and the assembly are ordered by ONE torch stream.  It must not be the legacy default
-    # stream: its handle is 0, which gs_config.stream reads as "create your own" - the context would then run unordered with
-    # the collective and the send buffer would be gathered before the blend has written it.
-    if world > 1:
-        torch.cuda.set_stream(torch.cuda.Stream(dev))
-    stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else None
+    eflag = _abi.GS_FLAG_EXACT_BLEND if args.exact else 0
+    flags = (0 if args.no_timing else _abi.GS_FLAG_TIMING) | eflag
     pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
     pg.numGaussians, pg.gaussiansBuffer, pg.sphericalHarmonicsDegree = N, splats, 3
-    r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags, cols=cols if world > 1 else None,
-                        stream=stream)
+    # the context that uploads the splats.  N = 1: the one that is timed.  N > 1: a whole-canvas context that only holds the
+    # replica, calibrates the slab bounds and renders the frame the assembled slabs are checked against; the timed slab
+    # contexts borrow its splats.
+    r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags if world == 1 else eflag)
     keep_scene = world == 1 and not args.no_cpu and ply_records is None  # the CPU baseline renders the same bits
     host_scene = splats.cpu().numpy() if keep_scene else ply_records
-    del splats, pg
+    del splats
+    pg.gaussiansBuffer = None
     torch.cuda.empty_cache()
-    if args.tile_cull >= 0:
-        r.set_option(_abi.GS_OPT_TILE_CULL, args.tile_cull)
+
+    def options(rr):
+        if args.tile_cull >= 0:
+            rr.set_option(_abi.GS_OPT_TILE_CULL, args.tile_cull)
+        if args.grid:
+            rr.set_option(_abi.GS_OPT_PERSISTENT_GRID, args.grid)
+        if args.emit_order >= 0:
+            rr.set_option(_abi.GS_OPT_EMIT_ORDER, args.emit_order)
+        if args.blend_ablation:
+            rr.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
+
+    options(r)
     if args.frames_in_flight > 0 and world == 1:
         r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
-    if args.grid:
-        r.set_option(_abi.GS_OPT_PERSISTENT_GRID, args.grid)
-    if args.emit_order >= 0:
-        r.set_option(_abi.GS_OPT_EMIT_ORDER, args.emit_order)
-    if args.blend_ablation:
-        r.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
-    xch = ovl = None
+    owner = xch = pipe = None
+    bounds = multigpu.slab_bounds(W, ts, world)  # tile-column slabs (SURVEY 8e)
     if world > 1:
-        xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, renderer=r)
-        if args.overlap_exchange:
-            ovl = multigpu.OverlappedExchange(xch, torch.cuda.current_stream(dev))
+        owner = r
+        if not args.even_slabs:
+            # slabs balanced by load: instances per tile column, summed over 8 cameras of the orbit, from whole-canvas frames
+            # (rank 0 decides, everybody takes its answer)
+            ntx_b = multigpu.num_tile_columns(W, ts)
+            col = np.zeros(ntx_b, dtype=np.float64)
+            if rank == 0:
+                for k in range(0, 64, 8):
+                    owner.render_uniforms(uniforms[k])
+                    owner.wait()
+                    tc = np.diff(np.concatenate([[0], owner.read_buffer(_abi.GS_BUF_RANGES).astype(np.int64)])).astype(np.float64)
+                    col += tc[: (tc.size // ntx_b) * ntx_b].reshape(-1, ntx_b).sum(axis=0)  # instances per tile, summed over the rows
+                bounds = multigpu.balanced_bounds(col, world)
+            tb = torch.tensor(bounds, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.broadcast(tb, src=0)
+            bounds = [int(v) for v in tb.tolist()]
+        cols = (bounds[rank], bounds[rank + 1])
+        xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, bounds=bounds, collective=args.collective)
+
+        def make_slab_renderer(stream_handle, share_with, fl=eflag):
+            rr = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=fl, cols=cols, stream=stream_handle, share_with=share_with)
+            options(rr)
+            return rr
+
+        # K frames in flight per rank: K slab contexts on their own streams, collectives in frame order on one more stream
+        pipe = multigpu.PipelinedSlabs(xch, make_slab_renderer, args.frames_in_flight if args.frames_in_flight > 0 else 3, owner=owner)
+        r = pipe.renderers[0]
 
     def step(k):
         u = uniforms[k % 64]
         if world == 1:
             r.render_uniforms(u)
-        elif ovl is not None:
-            r.render_uniforms(u, out_ptr=ovl.send_ptr())  # blend writes straight into this frame's send buffer
-            ovl.submit(assemble=(rank == 0))               # all-gather on the side stream; assembles the previous frame
         else:
-            r.render_uniforms(u, out_ptr=xch.send.data_ptr())  # blend writes straight into the send buffer
-            xch.exchange()                                      # one RCCL all-gather of the slabs over xGMI
-            if rank == 0:
-                xch.assemble()
+            pipe.submit(u)  # blend into the send buffer, gather to the presenting rank, assembly there: all enqueued, no host wait
 
     trouble = {}
 
     def sync():
-        if ovl is not None:
-            ovl.finish(assemble=(rank == 0))
         try:
-            r.wait()
+            if pipe is not None:
+                pipe.finish()
+            else:
+                r.wait()
         except _abi.GsError as e:
             if e.code != -9:  # GS_ERR_TRUNCATED: frames of this batch were rendered from truncated lists (capacity now grown)
                 raise
@@ -352,9 +374,10 @@ def main():
     # capacity calibration, outside warm-up and timing: every camera of the orbit once, waited for one by one, so that the
     # (key,value) arrays have grown to the largest frame of the orbit before frames are enqueued back to back (a frame that
     # overflows while others are queued behind it cannot be re-rendered: gs_wait reports GS_ERR_TRUNCATED)
-    for k in range(64):
-        r.render_uniforms(uniforms[k])
-        r.wait()
+    for rr in (pipe.renderers if pipe is not None else [r]):
+        for k in range(64):
+            rr.render_uniforms(uniforms[k])
+            rr.wait()
     for k in range(args.warmup):
         step(k)
     sync()
@@ -371,13 +394,36 @@ def main():
         dt = float(t.item())
     st = r.stats()
 
+    slab_strict = None
+    if world > 1 and rank == 0 and not args.no_timing:
+        # outside the timed region: rank 0's slab strictly one frame after the other on a context with per-stage hipEvents (no
+        # exchange): where `stages` and `roofline` of an N > 1 line come from
+        rt = make_slab_renderer(None, owner, flags)
+        for k in range(64):
+            rt.render_uniforms(uniforms[k])
+            rt.wait()
+        slab_strict = flight_pass(rt, _abi, uniforms, args, 1)
+        rt.destroy()
+
     verified = None
+    if world > 1 and not args.no_verify:
+        # every rank: the slab it sent last (still in its send buffer) against its columns of a whole-canvas render here
+        last_k = args.warmup + args.steps - 1
+        owner.render_uniforms(uniforms[last_k % 64])
+        owner.wait()
+        whole_local = torch.from_numpy(owner.read_rgba8())
+        b0, e0 = xch.pixels[rank]
+        mine = pipe.send[last_k % pipe.K][: H * (e0 - b0) * 4].view(H, e0 - b0, 4).cpu()
+        slab_ok = bool(torch.equal(mine, whole_local[:, b0:e0]))
+        if not slab_ok:
+            print("verify: rank %d: its own slab differs from the whole-canvas render in %d pixels" % (rank, int((mine != whole_local[:, b0:e0]).any(dim=2).sum())), file=sys.stderr, flush=True)
+        ok_t = torch.tensor([int(slab_ok)], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        slabs_ok = bool(int(ok_t.item()))
     if world > 1 and rank == 0 and not args.no_verify:
         # outside the timed region: the assembled last frame must equal a whole-canvas render of the same camera on this GPU
         # (the slabs only filter the key emission: byte-for-byte equality, tests/test_gpu_parity.py::test_slab_union...)
-        pgv = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
-        pgv.numGaussians, pgv.gaussiansBuffer = N, None
-        full = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pgv, ts, share_with=r)
+        full = owner
         full.render_uniforms(uniforms[(args.warmup + args.steps - 1) % 64])
         full.wait()
         whole = torch.from_numpy(full.read_rgba8())
@@ -385,9 +431,9 @@ def main():
         verified = bool(torch.equal(whole, got))
         if not verified:
             d = (whole != got).any(dim=2)
-            cols = torch.nonzero(d.any(dim=0)).flatten()
-            print("verify: %d differing pixels, columns %d..%d, slab pixel bounds %s" % (int(d.sum()), int(cols.min()), int(cols.max()), xch.pixels), file=sys.stderr, flush=True)
-        full.destroy()
+            bad = torch.nonzero(d.any(dim=0)).flatten()
+            print("verify: %d differing pixels, columns %d..%d, slab pixel bounds %s" % (int(d.sum()), int(bad.min()), int(bad.max()), xch.pixels), file=sys.stderr, flush=True)
+            print("verify: per-slab differing pixels vs the last frame: %s" % [int(d[:, b:e].sum()) for b, e in xch.pixels], file=sys.stderr, flush=True)
 
     if world > 1:
         # whole-frame statistics are the sums over the slabs
@@ -405,9 +451,10 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "ply" if args.ply else "synthetic",
             # frames are enqueued back to back (no host wait inside the timed region, one gs_wait at its end); the context keeps
             # this many of them in flight (GS_OPT_FRAMES_IN_FLIGHT: a shadow context with its own stream and per-frame arrays)
-            "frames_in_flight": st["frames_in_flight"],
+            "frames_in_flight": pipe.K if pipe is not None else st["frames_in_flight"],
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
-                       "parallelism": ("tile-column slabs x%d + all-gather%s" % (world, " overlapped with the next frame" if ovl is not None else ""))
+                       "parallelism": ("tile-column slabs x%d (%s, bounds %s) + RCCL %s of the rgba8 slabs to rank 0, %d frames in flight per rank"
+                                       % (world, "even" if args.even_slabs else "balanced by instance count", bounds, args.collective, pipe.K))
                        if world > 1 else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
                        "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),
@@ -416,6 +463,7 @@ def main():
         }
         if verified is not None:
             line["slab_frame_equals_single_gpu_frame"] = verified
+            line["every_rank_slab_equals_its_columns_of_the_single_gpu_frame"] = slabs_ok
         stq, stage_source = st, "the timed region"
         if world == 1 and st["frames_in_flight"] > 1 and not args.no_timing:
             # the timed region kept two frames in flight: the kernels of consecutive frames overlap there and stretch each other, so
@@ -426,6 +474,10 @@ def main():
             line["one_frame_in_flight"], stq = flight_pass(r, _abi, uniforms, args, 1)
             r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, st["frames_in_flight"])
             stage_source = "the same steps strictly one frame after the other (one_frame_in_flight), outside the timed region"
+        if slab_strict is not None:
+            line["one_frame_in_flight"], stq = slab_strict
+            line["one_frame_in_flight"]["note"] = "rank 0's slab alone, no exchange"
+            stage_source = "rank 0's slab strictly one frame after the other, outside the timed region"
         if not args.no_timing and stq["frames_timed"]:
             st_main, st = st, stq
             ab = algorithmic_bytes(st, W, H, T)
@@ -476,7 +528,11 @@ def main():
             # the reference itself (WGSL on a WebGPU runtime, TypeScript host) cannot run on this box
             line["webgpu_baseline"] = "unavailable (no WebGPU runtime, no TypeScript toolchain, no network)"
         print(json.dumps(line), flush=True)
-    r.destroy()
+    if pipe is not None:
+        pipe.destroy()
+        owner.destroy()
+    else:
+        r.destroy()
     if world > 1:
         dist.destroy_process_group()
 

@@ -406,13 +406,12 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
     if (c->emit_order == 2) {
-        // auto: the depth-ordered pipeline saves (passes - tile_passes) full sweeps of the instance arrays (16 B per
-        // instance each, ~3 TB/s) and the histogram pass, and costs ~100 us of gaussian-level kernels whose time does not
-        // shrink with the slab (a scan over all N counts, two small sweeps, a second scan).  Measured break-even with one
-        // sweep saved: I ~ 13 M (1080p whole canvas, 42 M: -135 us; 2-GPU slab, 21 M: -45 us; 4-GPU slab, 11 M: +10 us;
-        // 8-GPU slab, 5 M: +15 us), so: depth order once (sweeps saved) x (previous frame's I) >= 15 M.
+        // auto: the depth-ordered pipeline saves (passes - tile_passes) full sweeps of the instance arrays and the histogram
+        // pass, and costs the gaussian-level counting sort (three small kernels, k_gsort.hip).  Measured at config B: whole
+        // canvas (18.5 M instances) 1.42 vs 1.50 ms, one of 8 slabs (1.9-2.6 M) 418-508 vs 455-566 us, one of 4 slabs 586-699 vs
+        // 618-743 us per frame; below ~1 M instances both are launch-bound and the same.
         const uint64_t saved = c->passes > c->tile_passes ? c->passes - c->tile_passes : 0;
-        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 15000000ull);
+        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 1000000ull);
     } else {
         c->index_order = (c->emit_order == 1);
     }

@@ -124,6 +124,34 @@ __device__ __forceinline__ void sh_colour(const float4* __restrict__ rec, float 
     }
 }
 
+// in_frustum (process_gaussians.wgsl:108-125) and, for a tile-column slab, a conservative reach test on the position alone.
+__device__ __forceinline__ bool in_frustum_slab(const GsUniforms& u, const GsFrame& f, float x, float y, float z, float smax_log) {
+    float ph[4], pv[4];
+    m4_mulv(u.proj, x, y, z, ph);
+    const float pw = 1.0f / (ph[3] + 0.0000001f);
+    const float ndx = ph[0] * pw, ndy = ph[1] * pw;
+    m4_mulv(u.view, x, y, z, pv);
+    if ((pv[2] <= 0.2f) || (ndx <= -1.1f || ndx >= 1.1f || ndy <= -1.1f || ndy >= 1.1f)) return false;
+    if (f.full) return true;
+    // Tile-column slab: drop the gaussian here, before its record is touched, if even a conservative
+    // bound of its screen radius cannot reach this rank's columns.  lambda_max(cov2d) <= |J|_F^2 * s_max^2
+    // (W is orthonormal), |J|_F^2 <= (fx/z)^2 (1+limx^2) + (fy/z)^2 (1+limy^2) after the clamp of :180-186,
+    // and lambda_1 <= (a+c) + sqrt(0.1) <= 2*lambda_max(cov) + 0.92; margins cover the f32 rounding.
+    const float sm = __expf(smax_log) * u.scale_modifier * 1.001f;
+    const float limx = 1.3f * u.tan_fovx, limy = 1.3f * u.tan_fovy;
+    const float iz = 1.0f / pv[2];
+    const float jf2 = (u.focal_x * iz) * (u.focal_x * iz) * (1.0f + limx * limx) + (u.focal_y * iz) * (u.focal_y * iz) * (1.0f + limy * limy);
+    const float rb = 3.0f * __builtin_sqrtf(2.0f * jf2 * sm * sm + 0.92f) * 1.001f + 2.0f;
+    const float pxs = ((ndx * 0.5f) + 0.5f) * (float)f.width;
+    const float ts = (float)f.tile_size;
+    // instance columns lie in [floor(lo/ts), floor(hi/ts)] CLAMPED to [0, ntx] (getRect, :305-313): a splat
+    // entirely left of the screen still lands in column 0, one entirely right of it in column ntx (alias)
+    const float lo = pxs - rb, hi = pxs + rb;
+    const bool reach = (lo < (float)f.col1 * ts) && (f.col0 == 0u || hi >= (float)f.col0 * ts);
+    const bool alias = (f.col0 == 0u) && (hi >= (float)f.ntx * ts); // column ntx aliases to column 0
+    return (reach || alias) || !(rb == rb);
+}
+
 #define PRE_G 512 // gaussians per workgroup
 #ifndef PRE_WAVES
 #define PRE_WAVES 4 // waves per SIMD the register allocator must leave room for
@@ -143,12 +171,17 @@ __device__ __forceinline__ void sh_colour(const float4* __restrict__ rec, float 
 // TIGHT = true : the product path's opacity-aware binning (gs_tight.h): the tile count is the number of tiles of the rect that
 //                intersect the gaussian's alpha >= 1/255 ellipse (0 when its opacity is below 1/255), and the emission
 //                (gs_emit_tight_kernel) writes exactly those.  gs_render_debug and GS_OPT_TILE_CULL 0 use TIGHT = false.
-template <bool FUSED, bool TIGHT = false>
+// NB           : 512-gaussian chunks per workgroup.  A tile-column slab keeps ~1/G of the frustum survivors, so with one
+//                chunk per workgroup the dense phases would run on a few dozen lanes each, one latency-bound workgroup after
+//                the other (131-145 us per rank at 8 slabs, the O(N) part that does not shrink with the slab).  With NB = 8
+//                a workgroup culls 4 096 gaussians (positions of 8 per thread in flight at a time), appends the survivors to
+//                ONE list in LDS and then runs the dense phases on full waves.
+template <bool FUSED, bool TIGHT = false, int NB = 1>
 __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
                                                              uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ keys,
                                                              uint32_t* __restrict__ values, unsigned long long* status,
                                                              uint32_t* ticket, GsControl* ctl) {
-    __shared__ uint32_t s_ids[PRE_G];
+    __shared__ uint32_t s_ids[PRE_G * NB];
     __shared__ uint32_t s_cnt[2][4];
     __shared__ uint32_t s_ecnt[FUSED ? PRE_G : 1]; // tile count, then exclusive prefix, of the v-th survivor
     __shared__ uint32_t s_erow[FUSED ? PRE_G : 1]; // xa | wmain<<16 | alias<<31
@@ -166,62 +199,74 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         __syncthreads();
         bid = s_misc[0];
     }
-    const uint32_t base = bid * PRE_G;
+    const uint32_t base = bid * (PRE_G * NB);
 
     // ---- phase 1: in_frustum (:108-125) on the position planes, survivors compacted ----
-    bool vis[2];
-    unsigned long long bal[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const uint32_t i = base + k * 256 + tid;
-        vis[k] = false;
-        if (i < f.n) {
-            const float x = s.px[i], y = s.py[i], z = s.pz[i];
-            float ph[4], pv[4];
-            m4_mulv(u.proj, x, y, z, ph);
-            const float pw = 1.0f / (ph[3] + 0.0000001f);
-            const float ndx = ph[0] * pw, ndy = ph[1] * pw;
-            m4_mulv(u.view, x, y, z, pv);
-            vis[k] = !((pv[2] <= 0.2f) || (ndx <= -1.1f || ndx >= 1.1f || ndy <= -1.1f || ndy >= 1.1f));
-            if (vis[k] && !f.full) {
-                // Tile-column slab: drop the gaussian here, before its record is touched, if even a conservative
-                // bound of its screen radius cannot reach this rank's columns.  lambda_max(cov2d) <= |J|_F^2 * s_max^2
-                // (W is orthonormal), |J|_F^2 <= (fx/z)^2 (1+limx^2) + (fy/z)^2 (1+limy^2) after the clamp of :180-186,
-                // and lambda_1 <= (a+c) + sqrt(0.1) <= 2*lambda_max(cov) + 0.92; margins cover the f32 rounding.
-                const float sm = __expf(s.smax[i]) * u.scale_modifier * 1.001f;
-                const float limx = 1.3f * u.tan_fovx, limy = 1.3f * u.tan_fovy;
-                const float iz = 1.0f / pv[2];
-                const float jf2 = (u.focal_x * iz) * (u.focal_x * iz) * (1.0f + limx * limx) + (u.focal_y * iz) * (u.focal_y * iz) * (1.0f + limy * limy);
-                const float rb = 3.0f * __builtin_sqrtf(2.0f * jf2 * sm * sm + 0.92f) * 1.001f + 2.0f;
-                const float pxs = ((ndx * 0.5f) + 0.5f) * (float)f.width;
-                const float ts = (float)f.tile_size;
-                // instance columns lie in [floor(lo/ts), floor(hi/ts)] CLAMPED to [0, ntx] (getRect, :305-313): a splat
-                // entirely left of the screen still lands in column 0, one entirely right of it in column ntx (alias)
-                const float lo = pxs - rb, hi = pxs + rb;
-                const bool reach = (lo < (float)f.col1 * ts) && (f.col0 == 0u || hi >= (float)f.col0 * ts);
-                const bool alias = (f.col0 == 0u) && (hi >= (float)f.ntx * ts); // column ntx aliases to column 0
-                if (!(reach || alias) && (rb == rb)) { vis[k] = false; }
-            }
-            if (!vis[k]) tile_counts[i] = 0u;
-        }
-        bal[k] = __ballot(vis[k]);
-        if (lane == 0) s_cnt[k][w] = (uint32_t)__popcll(bal[k]);
-    }
-    __syncthreads();
     uint32_t nvis = 0;
+    if (NB > 1) {
+        // (slabs only) survivors are appended wave by wave through one LDS counter: their order in the list is free, every
+        // output of the unfused kernel is indexed by the gaussian
+        if (tid == 0) s_misc[1] = 0u;
+        __syncthreads();
+#pragma unroll 1
+        for (int h = 0; h < NB / 4; ++h) {
+            float X[8], Y[8], Z[8], S[8];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        uint32_t before = 0;
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + (uint32_t)(h * 8 + k) * 256u + tid;
+                const bool in = i < f.n;
+                X[k] = in ? s.px[i] : 0.0f; Y[k] = in ? s.py[i] : 0.0f; Z[k] = in ? s.pz[i] : 0.0f; S[k] = in ? s.smax[i] : 0.0f;
+            }
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const uint32_t c = s_cnt[k][ww];
-            if (ww < (int)w) before += c;
-            nvis += c;
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t off = (uint32_t)(h * 8 + k) * 256u + tid;
+                const uint32_t i = base + off;
+                bool v = false;
+                if (i < f.n) {
+                    v = in_frustum_slab(u, f, X[k], Y[k], Z[k], S[k]);
+                    if (!v) tile_counts[i] = 0u;
+                }
+                const unsigned long long b = __ballot(v);
+                if (b) {
+                    uint32_t at = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(b)) at = atomicAdd(&s_misc[1], (uint32_t)__popcll(b));
+                    at = (uint32_t)__builtin_amdgcn_readlane((int)at, __builtin_ctzll(b));
+                    if (v) s_ids[at + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = off;
+                }
+            }
         }
-        if (k == 1) before += s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-        if (vis[k]) s_ids[before + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] = k * 256 + tid;
+        __syncthreads();
+        nvis = s_misc[1];
+    } else {
+        bool vis[2];
+        unsigned long long bal[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t i = base + k * 256 + tid;
+            vis[k] = false;
+            if (i < f.n) {
+                vis[k] = in_frustum_slab(u, f, s.px[i], s.py[i], s.pz[i], f.full ? 0.0f : s.smax[i]);
+                if (!vis[k]) tile_counts[i] = 0u;
+            }
+            bal[k] = __ballot(vis[k]);
+            if (lane == 0) s_cnt[k][w] = (uint32_t)__popcll(bal[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint32_t before = 0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const uint32_t c = s_cnt[k][ww];
+                if (ww < (int)w) before += c;
+                nvis += c;
+            }
+            if (k == 1) before += s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+            if (vis[k]) s_ids[before + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] = k * 256 + tid;
+        }
+        __syncthreads();
+
     }
-    __syncthreads();
 
     // ---- phases 2 and 3: one survivor per lane ----
     const uint32_t trips = (nvis + 255u) / 256u;
@@ -470,14 +515,17 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
 }
 void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, bool tight,
                           hipStream_t st) {
-    const uint32_t blocks = (f.n + PRE_G - 1) / PRE_G;
-    if (!blocks) return;
-    if (tight)
-        hipLaunchKernelGGL((gs_preprocess_kernel<false, true>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr);
-    else
-        hipLaunchKernelGGL((gs_preprocess_kernel<false, false>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr);
+    if (!f.n) return;
+    // chunks per workgroup (see NB): 8 for a slab narrower than 30 % of the canvas, 4 up to 75 %, else 1
+    const uint32_t wcols = f.col1 - f.col0;
+    const uint32_t nb = f.full || wcols * 4u > f.ntx * 3u ? 1u : (wcols * 10u > f.ntx * 3u ? 4u : 8u);
+    const uint32_t blocks = (f.n + PRE_G * nb - 1) / (PRE_G * nb);
+#define GS_PRE_LAUNCH(T, NBV)                                                                                                        \
+    hipLaunchKernelGGL((gs_preprocess_kernel<false, T, NBV>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr, \
+                       (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr)
+    if (tight) { if (nb == 8u) GS_PRE_LAUNCH(true, 8); else if (nb == 4u) GS_PRE_LAUNCH(true, 4); else GS_PRE_LAUNCH(true, 1); }
+    else { if (nb == 8u) GS_PRE_LAUNCH(false, 8); else if (nb == 4u) GS_PRE_LAUNCH(false, 4); else GS_PRE_LAUNCH(false, 1); }
+#undef GS_PRE_LAUNCH
 }
 uint32_t gs_project_emit_blocks(uint32_t n) { return (n + PRE_G - 1) / PRE_G; }
 // projection + scan + emission in one launch; status: gs_project_emit_blocks(n) zeroed 8-byte words, ticket: one zeroed word

@@ -22,6 +22,33 @@ def slab_bounds(width, tile_size, world):
     return [ntx * g // world for g in range(world + 1)]
 
 
+def balanced_bounds(col_cost, world):
+    """Tile-column boundaries (world+1 entries) of the contiguous partition whose most expensive slab is cheapest.
+    `col_cost[x]` = cost of tile column x, e.g. its instance count in a calibration frame (the per-tile counts of a whole-canvas
+    render summed over the rows): a rank's frame time is a fixed part plus a part proportional to its instances, and the
+    centre columns of a scene hold several times the instances of the border columns.  Every slab gets >= 1 column."""
+    cost = np.asarray(col_cost, dtype=np.float64).reshape(-1)
+    ntx = cost.shape[0]
+    if world > ntx:
+        raise ValueError("more ranks (%d) than tile columns (%d)" % (world, ntx))
+    pre = np.concatenate([[0.0], np.cumsum(cost)])
+    # best[g][x] = smallest possible maximum over g slabs covering columns [0, x)
+    inf = float("inf")
+    best = np.full((world + 1, ntx + 1), inf)
+    cut = np.zeros((world + 1, ntx + 1), dtype=np.int64)
+    best[0][0] = 0.0
+    for g in range(1, world + 1):
+        for x in range(g, ntx - (world - g) + 1):
+            for y in range(g - 1, x):  # the last slab is [y, x)
+                v = max(best[g - 1][y], pre[x] - pre[y])
+                if v < best[g][x]:
+                    best[g][x], cut[g][x] = v, y
+    bounds = [ntx]
+    for g in range(world, 0, -1):
+        bounds.append(int(cut[g][bounds[-1]]))
+    return bounds[::-1]
+
+
 def slab_pixels(bounds, width, tile_size):
     """Pixel [begin, end) of every slab."""
     return [(b0 * tile_size, min(width, b1 * tile_size)) for b0, b1 in zip(bounds[:-1], bounds[1:])]
@@ -31,11 +58,19 @@ class SlabExchange:
     """Gathers per-rank slab images and assembles the frame.  Works on any torch.distributed backend
     (tested with gloo on CPU); on GPUs the assembly runs in the library (gs_assemble_slabs)."""
 
-    def __init__(self, width, height, tile_size, world, rank, device, renderer=None):
+    def __init__(self, width, height, tile_size, world, rank, device, renderer=None, bounds=None, collective="all_gather", root=0):
+        """bounds: tile-column boundaries (default: even slabs).  collective: "all_gather" (every rank ends up with every slab) or
+        "gather" (only `root`, the presenting rank, receives them: RCCL send/recv to the root, 1/world of the fabric bytes)."""
         import torch
         self.torch = torch
         self.W, self.H, self.ts, self.world, self.rank = width, height, tile_size, world, rank
-        self.bounds = slab_bounds(width, tile_size, world)
+        self.bounds = list(bounds) if bounds is not None else slab_bounds(width, tile_size, world)
+        if len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != num_tile_columns(width, tile_size) \
+                or any(a >= b for a, b in zip(self.bounds, self.bounds[1:])):
+            raise ValueError("bad slab bounds %r" % (self.bounds,))
+        if collective not in ("all_gather", "gather"):
+            raise ValueError("collective must be all_gather or gather")
+        self.collective, self.root = collective, root
         self.pixels = slab_pixels(self.bounds, width, tile_size)
         self.max_w = max(e - b for b, e in self.pixels)
         self.stride = height * self.max_w * 4  # bytes per rank in the gathered buffer
@@ -56,16 +91,23 @@ class SlabExchange:
         gathered = self.gathered if gathered is None else gathered
         if self.world == 1:
             gathered.copy_(send)
+        elif self.collective == "gather" and not (dist.get_backend() == "gloo" and send.is_cuda):
+            # only the presenting rank needs the slabs (gloo cannot gather device tensors: the rehearsal path below all-gathers)
+            parts = list(gathered.view(self.world, self.stride).unbind(0)) if self.rank == self.root else None
+            dist.gather(send, parts, dst=self.root)
         elif dist.get_backend() == "gloo":
-            # rehearsal path (CPU tests, several ranks on one GPU): gloo stages device tensors through the host on streams of its
-            # own, so the frame has to be complete before it reads `send` and its copies back into `gathered` have to be complete
-            # before the assembly reads them (with 4 ranks on one GPU the unsynchronised form assembled stale slabs)
+            # rehearsal path (CPU tests, several ranks on one GPU): device tensors are staged through the host here, with
+            # blocking copies around a CPU all-gather, so the rehearsal checks the frame logic and nothing of gloo's own
+            # device-tensor handling
             if send.is_cuda:
+                self.torch.cuda.synchronize(send.device)  # the frame is complete
+                host = send.cpu()
+                parts = [self.torch.empty_like(host) for _ in range(self.world)]
+                dist.all_gather(parts, host)
+                gathered.copy_(self.torch.cat(parts))
                 self.torch.cuda.synchronize(send.device)
-            parts = list(gathered.view(self.world, self.stride).unbind(0))
-            dist.all_gather(parts, send)
-            if send.is_cuda:
-                self.torch.cuda.synchronize(send.device)
+            else:
+                dist.all_gather(list(gathered.view(self.world, self.stride).unbind(0)), send)
         else:
             dist.all_gather_into_tensor(gathered, send)
 
@@ -133,3 +175,74 @@ class OverlappedExchange:
             else:
                 self.render_stream.wait_event(self.ev_gather[self.unassembled])
             self.unassembled = None
+
+
+class PipelinedSlabs:
+    """K frames in flight on every rank.  A rank's slab frame is bound by latencies, not by throughput (its longest tile list, a
+    dozen dependent launches), so one frame at a time leaves most of the GPU idle: 418-508 us per frame at 8 slabs of config B
+    against 211-275 us with three frames in flight (tools/slab_flight_probe.py).  K slab contexts share the resident splats
+    (gs_share_splats), each on its own stream with its own send buffer; frame k is rendered by context k % K, its collective
+    and (on the root) the assembly are queued on ONE communication stream in frame order -- the same order on every rank, as
+    RCCL requires -- after the frame's event, and the context's next frame (k + K) waits for that collective to have read the
+    send buffer.  No host synchronisation inside the frame loop.
+    make_renderer(stream_handle, share_with) -> a slab Renderer on that stream (share_with = None: it uploads the splats)."""
+
+    def __init__(self, xch, make_renderer, frames_in_flight=3, owner=None):
+        torch = xch.torch
+        self.x, self.torch = xch, torch
+        self.K = int(frames_in_flight)
+        if self.K < 1:
+            raise ValueError("frames_in_flight must be >= 1")
+        self.streams = [torch.cuda.Stream(xch.device) for _ in range(self.K)]
+        self.comm = torch.cuda.Stream(xch.device)
+        self.renderers = []
+        for k in range(self.K):
+            self.renderers.append(make_renderer(self.streams[k].cuda_stream, owner if owner is not None else (self.renderers[0] if k else None)))
+        share = owner if owner is not None else self.renderers[0]
+        # the assembly (gs_assemble_slabs) runs on its context's stream: a context of its own on the communication stream
+        self.assembler = make_renderer(self.comm.cuda_stream, share) if xch.rank == xch.root else None
+        if self.assembler is not None:
+            xch.renderer = self.assembler
+        self.send = [xch.send] + [torch.zeros_like(xch.send) for _ in range(self.K - 1)]
+        self.ev_render = [torch.cuda.Event() for _ in range(self.K)]
+        self.ev_free = [None] * self.K
+        self.k = 0
+
+    def submit(self, uniforms):
+        torch = self.torch
+        slot = self.k % self.K
+        s = self.streams[slot]
+        if self.ev_free[slot] is not None:
+            s.wait_event(self.ev_free[slot])  # the collective of frame k - K has read this send buffer
+        self.renderers[slot].render_uniforms(uniforms, out_ptr=self.send[slot].data_ptr())  # the blend writes the send buffer
+        self.ev_render[slot].record(s)
+        self.comm.wait_event(self.ev_render[slot])
+        with torch.cuda.stream(self.comm):
+            self.x.exchange(self.send[slot], self.x.gathered)
+            if self.assembler is not None:
+                self.x.assemble(self.x.gathered)
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+        self.ev_free[slot] = ev
+        self.k += 1
+        return slot
+
+    def finish(self):
+        """Drains every context and the communication stream; raises what gs_wait raises (GS_ERR_TRUNCATED ...)."""
+        err = None
+        for r in self.renderers:
+            try:
+                r.wait()
+            except Exception as e:  # keep draining: the other contexts still hold frames
+                err = err or e
+        self.comm.synchronize()
+        if err is not None:
+            raise err
+
+    def destroy(self):
+        if self.assembler is not None:
+            self.assembler.destroy()
+            self.assembler = None
+        for r in reversed(self.renderers):
+            r.destroy()
+        self.renderers = []

@@ -85,6 +85,11 @@ class Renderer:
         if share_with is not None:
             check(self._L.gs_share_splats(self._ctx, share_with._ctx))
         elif hasattr(buf, "data_ptr"):  # a device tensor: no PCIe copy
+            # the repack runs on the context's stream, which is not ordered against the stream that produced the tensor:
+            # the records must be complete before the call (a scene still being generated was repacked half-written when
+            # several processes shared one GPU)
+            import torch
+            torch.cuda.current_stream(buf.device).synchronize()
             check(self._L.gs_upload_splats_device(self._ctx, buf.data_ptr(), self.numGaussians))
         else:
             arr = np.ascontiguousarray(buf, dtype=np.float32)

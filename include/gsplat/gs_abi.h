@@ -143,7 +143,9 @@ int32_t gs_ply_load(const char* path, void** records, uint64_t* n, int32_t* sh_d
 void gs_ply_free(void* records);
 /* gs_ply_load + gs_upload_splats. */
 int32_t gs_upload_ply(gs_ctx* ctx, const char* path, uint64_t* n);
-/* Same, from a device pointer (no PCIe copy). */
+/* Same, from a device pointer (no PCIe copy).  The records must be COMPLETE when the call is made: the repack runs on the
+ * context's stream and is not ordered against whatever stream produced them (synchronise the producer first).  Returns
+ * after the repack; the caller may free d_aos320 then. */
 int32_t gs_upload_splats_device(gs_ctx* ctx, const void* d_aos320, uint64_t n);
 /* `ctx` renders `owner`'s resident splats (same device; read-only during a frame) with its own stream and per-frame
  * buffers: several contexts rendered round-robin keep several frames in flight, so one frame's blend (instruction-issue

@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, W, H, ts, out):
+def _worker(rank, world, port, W, H, ts, out, collective="all_gather", balanced=False):
     sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-wgpu_amd"))
     sys.path.insert(0, ROOT)
     import torch
@@ -23,13 +23,23 @@ def _worker(rank, world, port, W, H, ts, out):
     gs_oracle.set_num_threads(2)
     s = synth.bicycle_like(6000)
     u = synth.orbit_camera(9, W, H).uniforms(W, H)
-    x = multigpu.SlabExchange(W, H, ts, world, rank, torch.device("cpu"))
+    bounds = None
+    if balanced:  # slabs of unequal width: columns weighted by the whole frame's instance counts (rank 0 decides)
+        ntx = multigpu.num_tile_columns(W, ts)
+        tb = torch.zeros(world + 1, dtype=torch.int64)
+        if rank == 0:
+            full0 = gs_oracle.render(s, u, W, H, ts, want_f32=False)
+            tc = np.diff(np.concatenate([[0], full0["ranges"].astype(np.int64)]))
+            tb = torch.tensor(multigpu.balanced_bounds(tc[: (tc.size // ntx) * ntx].reshape(-1, ntx).sum(0), world), dtype=torch.int64)
+        dist.broadcast(tb, src=0)
+        bounds = [int(v) for v in tb.tolist()]
+    x = multigpu.SlabExchange(W, H, ts, world, rank, torch.device("cpu"), bounds=bounds, collective=collective)
     r = gs_oracle.render(s, u, W, H, ts, cols=x.cols, want_f32=False)
     b, e = x.pixels[rank]
     slab = np.ascontiguousarray(r["rgba8"][:, b:e])
     x.send[: slab.size] = torch.from_numpy(slab.reshape(-1))
     x.exchange()
-    img = x.assemble().numpy()
+    img = x.assemble().numpy() if (collective == "all_gather" or rank == 0) else None
     tot = torch.tensor([r["num_intersections"]], dtype=torch.int64)
     dist.all_reduce(tot)
     if rank == 0:
@@ -47,6 +57,38 @@ def test_slab_exchange_gloo(tmp_path, world, W, H, ts):
     ok = np.load(out)
     assert ok[0] == 1, "assembled frame differs from the single-device frame"
     assert ok[1] == 1, "slab intersection counts do not add up"
+
+
+@pytest.mark.parametrize("world,W,H,ts", [(2, 320, 160, 16), (3, 200, 96, 8)])
+def test_root_gather_and_balanced_slabs_gloo(tmp_path, world, W, H, ts):
+    """The collective bench.py uses at N > 1 (slabs to the presenting rank only) over slabs of unequal width."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + 20 + world
+    mp.spawn(_worker, args=(world, port, W, H, ts, out, "gather", True), nprocs=world, join=True)
+    ok = np.load(out)
+    assert ok[0] == 1, "assembled frame differs from the single-device frame"
+    assert ok[1] == 1, "slab intersection counts do not add up"
+
+
+def test_balanced_bounds():
+    from itertools import combinations
+    from gsplat import multigpu
+    rng = np.random.default_rng(5)
+    assert multigpu.balanced_bounds(np.ones(120), 8) == multigpu.slab_bounds(1920, 16, 8)
+    for ntx, world in [(7, 3), (9, 4), (12, 5), (10, 1), (6, 6)]:
+        cost = rng.integers(0, 50, ntx).astype(np.float64)
+        b = multigpu.balanced_bounds(cost, world)
+        assert b[0] == 0 and b[-1] == ntx and len(b) == world + 1 and all(x < y for x, y in zip(b, b[1:]))
+        got = max(cost[x:y].sum() for x, y in zip(b, b[1:]))
+        best = min(max(cost[x:y].sum() for x, y in zip((0,) + c, c + (ntx,))) for c in combinations(range(1, ntx), world - 1))
+        assert got == best
+    hill = np.exp(-0.5 * ((np.arange(120) - 60) / 25.0) ** 2)  # a scene's centre columns carry most instances
+    b = multigpu.balanced_bounds(hill, 8)
+    w = np.diff(b)
+    assert w[0] > w[3] and w[-1] > w[4], "border slabs must come out wider than centre slabs"
+    with pytest.raises(ValueError):
+        multigpu.balanced_bounds(np.ones(4), 5)
 
 
 def test_slab_bounds():
@@ -160,3 +202,56 @@ def test_device_side_exchange_is_ordered_with_the_frame(tmp_path, overlap):
     port = 29500 + (os.getpid() % 2000) + 11
     mp.spawn(_gpu_stream_worker, args=(2, port + int(overlap), 640, 368, 16, out, overlap), nprocs=2, join=True)
     assert np.load(out)[0] == 1
+
+
+def _gpu_pipeline_worker(rank, world, port, W, H, ts, out, K):
+    """bench.py's N > 1 step: K slab contexts per rank in flight (multigpu.PipelinedSlabs), slabs balanced by instance count,
+    gather to rank 0, assembly on the communication stream; seven frames without a host wait."""
+    import torch
+    import torch.distributed as dist
+    import gsplat
+    from gsplat import _abi, multigpu, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    s = synth.bicycle_like(60000)
+    us = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(7)]
+    pg = gsplat.PackedGaussians(s)
+    owner = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts)
+    ntx = multigpu.num_tile_columns(W, ts)
+    tb = torch.zeros(world + 1, dtype=torch.int64)
+    if rank == 0:
+        owner.render_uniforms(us[0])
+        owner.wait()
+        tc = np.diff(np.concatenate([[0], owner.read_buffer(_abi.GS_BUF_RANGES).astype(np.int64)])).astype(np.float64)
+        tb = torch.tensor(multigpu.balanced_bounds(tc[: (tc.size // ntx) * ntx].reshape(-1, ntx).sum(0), world), dtype=torch.int64)
+    dist.broadcast(tb, src=0)
+    bounds = [int(v) for v in tb.tolist()]
+    x = multigpu.SlabExchange(W, H, ts, world, rank, dev, bounds=bounds, collective="gather")
+    mk = lambda stream, share: gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts, cols=x.cols, stream=stream, share_with=share)
+    pipe = multigpu.PipelinedSlabs(x, mk, K, owner=owner)
+    for u in us:
+        pipe.submit(u)
+    pipe.finish()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    if rank == 0:
+        owner.render_uniforms(us[-1])
+        owner.wait()
+        np.save(out, np.array([int(np.array_equal(x.image.cpu().numpy(), owner.read_rgba8())), int(len(set(np.diff(bounds))) > 1)]))
+    pipe.destroy()
+    owner.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 3])
+def test_pipelined_slabs_on_one_gpu(tmp_path, K):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + 30 + K
+    mp.spawn(_gpu_pipeline_worker, args=(2, port, 640, 368, 16, out, K), nprocs=2, join=True)
+    ok = np.load(out)
+    assert ok[0] == 1, "the assembled last frame differs from the whole-canvas frame"
