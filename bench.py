@@ -231,6 +231,11 @@ def main():
     ap.add_argument("--tile-cull", type=int, default=-1, help="GS_OPT_TILE_CULL override (1 = tight binning, default; 0 = the reference's rect binning)")
     ap.add_argument("--collective", default="gather", choices=["gather", "all_gather"],
                     help="N>1: slabs go to the presenting rank only (RCCL send/recv to rank 0, default) or to every rank")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="GS_OPT_FRAME_GRAPH (1: replay the captured frame with one hipGraphLaunch; contexts with stage timing issue "
+                         "their launches directly whatever this says).  Default 0: measured no faster on this stack (config A 14.1 k "
+                         "vs 14.6 k frames/s: hipGraphLaunch of 16 nodes costs the host what 16 launches do)")
+    ap.add_argument("--force-multi", action="store_true", help="rehearsal: run the N > 1 code path with a world of one rank")
     ap.add_argument("--even-slabs", action="store_true",
                     help="N>1: equal tile-column slabs instead of slabs balanced by the instance counts of a calibration pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
@@ -263,14 +268,19 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    # --force-multi: the N > 1 code path (slab contexts in flight, collective on the communication stream, assembly) in a
+    # single process with a world of one: the only way to put the RCCL calls through their paces on a one-GPU box
+    multi = world > 1 or args.force_multi
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:  # --force-multi without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29571"), RANK="0", WORLD_SIZE="1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
@@ -294,8 +304,8 @@ def main():
     # the context that uploads the splats.  N = 1: the one that is timed.  N > 1: a whole-canvas context that only holds the
     # replica, calibrates the slab bounds and renders the frame the assembled slabs are checked against; the timed slab
     # contexts borrow its splats.
-    r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags if world == 1 else eflag)
-    keep_scene = world == 1 and not args.no_cpu and ply_records is None  # the CPU baseline renders the same bits
+    r = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=flags if not multi else eflag)
+    keep_scene = not multi and not args.no_cpu and ply_records is None  # the CPU baseline renders the same bits
     host_scene = splats.cpu().numpy() if keep_scene else ply_records
     del splats
     pg.gaussiansBuffer = None
@@ -310,15 +320,17 @@ def main():
             rr.set_option(_abi.GS_OPT_EMIT_ORDER, args.emit_order)
         if args.blend_ablation:
             rr.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
+        if args.graph >= 0:
+            rr.set_option(_abi.GS_OPT_FRAME_GRAPH, args.graph)
 
     options(r)
-    if args.frames_in_flight > 0 and world == 1:
+    if args.frames_in_flight > 0 and not multi:
         r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, args.frames_in_flight)
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
     owner = xch = pipe = None
     bounds = multigpu.slab_bounds(W, ts, world)  # tile-column slabs
-    if world > 1:
+    if multi:
         owner = r
         if not args.even_slabs:
             # slabs balanced by load: instances per tile column, summed over 8 cameras of the orbit, from whole-canvas frames
@@ -337,6 +349,7 @@ def main():
             bounds = [int(v) for v in tb.tolist()]
         cols = (bounds[rank], bounds[rank + 1])
         xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, bounds=bounds, collective=args.collective)
+        xch.always_collective = args.force_multi  # a world of one would otherwise copy instead of calling the collective
 
         def make_slab_renderer(stream_handle, share_with, fl=eflag):
             rr = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=fl, cols=cols, stream=stream_handle, share_with=share_with)
@@ -349,7 +362,7 @@ def main():
 
     def step(k):
         u = uniforms[k % 64]
-        if world == 1:
+        if not multi:
             r.render_uniforms(u)
         else:
             pipe.submit(u)  # blend into the send buffer, gather to the presenting rank, assembly there: all enqueued, no host wait
@@ -367,7 +380,7 @@ def main():
                 raise
             trouble["truncated"] = str(e)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -388,14 +401,14 @@ def main():
         step(args.warmup + k)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = r.stats()
 
     slab_strict = None
-    if world > 1 and rank == 0 and not args.no_timing:
+    if multi and rank == 0 and not args.no_timing:
         # outside the timed region: rank 0's slab strictly one frame after the other on a context with per-stage hipEvents (no
         # exchange): where `stages` and `roofline` of an N > 1 line come from
         rt = make_slab_renderer(None, owner, flags)
@@ -406,7 +419,7 @@ def main():
         rt.destroy()
 
     verified = None
-    if world > 1 and not args.no_verify:
+    if multi and not args.no_verify:
         # every rank: the slab it sent last (still in its send buffer) against its columns of a whole-canvas render here
         last_k = args.warmup + args.steps - 1
         owner.render_uniforms(uniforms[last_k % 64])
@@ -420,7 +433,7 @@ def main():
         ok_t = torch.tensor([int(slab_ok)], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         slabs_ok = bool(int(ok_t.item()))
-    if world > 1 and rank == 0 and not args.no_verify:
+    if multi and rank == 0 and not args.no_verify:
         # outside the timed region: the assembled last frame must equal a whole-canvas render of the same camera on this GPU
         # (the slabs only filter the key emission: byte-for-byte equality, tests/test_gpu_parity.py::test_slab_union...)
         full = owner
@@ -435,7 +448,7 @@ def main():
             print("verify: %d differing pixels, columns %d..%d, slab pixel bounds %s" % (int(d.sum()), int(bad.min()), int(bad.max()), xch.pixels), file=sys.stderr, flush=True)
             print("verify: per-slab differing pixels vs the last frame: %s" % [int(d[:, b:e].sum()) for b, e in xch.pixels], file=sys.stderr, flush=True)
 
-    if world > 1:
+    if multi:
         # whole-frame statistics are the sums over the slabs
         v = torch.tensor([st["num_visible"], st["num_intersections"], st["num_processed"]], dtype=torch.int64, device=dev)
         dist.all_reduce(v)
@@ -455,7 +468,7 @@ def main():
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
                        "parallelism": ("tile-column slabs x%d (%s, bounds %s) + RCCL %s of the rgba8 slabs to rank 0, %d frames in flight per rank"
                                        % (world, "even" if args.even_slabs else "balanced by instance count", bounds, args.collective, pipe.K))
-                       if world > 1 else "single GPU",
+                       if multi else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
                        "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),
                        "tight_binning": bool(st["tight_binning"]), "blend_mode": "exact" if args.exact else "fused",
@@ -465,7 +478,7 @@ def main():
             line["slab_frame_equals_single_gpu_frame"] = verified
             line["every_rank_slab_equals_its_columns_of_the_single_gpu_frame"] = slabs_ok
         stq, stage_source = st, "the timed region"
-        if world == 1 and st["frames_in_flight"] > 1 and not args.no_timing:
+        if not multi and st["frames_in_flight"] > 1 and not args.no_timing:
             # the timed region kept two frames in flight: the kernels of consecutive frames overlap there and stretch each other, so
             # a stage's hipEvent bracket is not a kernel duration any more.  The same steps are run once more, outside the timed
             # region, strictly one frame after the other: its per-stage times (and the frames/s of that discipline) are what
@@ -489,12 +502,12 @@ def main():
             dom = max(st["stage_us_mean"], key=lambda k_: st["stage_us_mean"][k_])
             dus = st["stage_us_mean"][dom]
             ach = ab[dom] / (dus * 1e-6) / 1e9
-            traffic, tdetail = pmc_traffic(dom, cfg["name"]) if world == 1 and not args.gaussians else (None, None)
+            traffic, tdetail = pmc_traffic(dom, cfg["name"]) if not multi and not args.gaussians else (None, None)
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": tdetail,
                                 "alg_bytes_per_launch": int(ab[dom]),
                                 "launch_us": round(dus, 2), "frames_timed": st["frames_timed"], "measured_in": stage_source,
-                                "rank0_slab_only": world > 1}
+                                "rank0_slab_only": multi}
             bus = st["stage_us_mean"]["blend"]
             if bus > 0:
                 # 22 flop + 1 exp (counted 2) per pixel x entry actually evaluated (64 pixels per surviving (8x8 block, entry) pair)
@@ -515,9 +528,9 @@ def main():
         if st["truncated_frames"] or trouble:
             line["valid"] = False  # a timed frame was rendered from truncated lists: the number does not count
             line["invalid_reason"] = trouble.get("truncated", "truncated frames")
-        if world == 1 and not args.no_verify:
+        if not multi and not args.no_verify:
             line.update(self_check(gsplat, _abi, r, W, H, ts, local_rank, uniforms[(args.warmup + args.steps - 1) % 64], args))
-        if world == 1 and not args.no_cpu:
+        if not multi and not args.no_cpu:
             u_last = uniforms[(args.warmup + args.steps - 1) % 64]
             line["cpu_baseline"], ref = cpu_baseline(host_scene, N, W, H, ts, u_last, args.cpu_max)
             if ref is not None and "exact_frame" in _KEEP:
@@ -533,7 +546,7 @@ def main():
         owner.destroy()
     else:
         r.destroy()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -3,8 +3,16 @@
 #include "gs_device.h"
 
 void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream_t st);
-void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, bool tight,
-                          hipStream_t st);
+struct GsPreprocessLaunch { // the projection's launch as data (its uniforms are the only kernel arguments that change per frame)
+    const void* func;
+    uint32_t blocks;
+    GsScene s; GsUniforms u; GsFrame f;
+    void* gdata; uint32_t* counts; uint32_t* keys; uint32_t* values; unsigned long long* status; uint32_t* ticket; GsControl* ctl;
+    void* args[10];
+};
+void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
+                           bool tight);
+void gs_launch_preprocess(GsPreprocessLaunch& L, hipStream_t st);
 uint32_t gs_project_emit_blocks(uint32_t n);
 void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, uint32_t* keys,
                             uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st);

@@ -141,6 +141,16 @@ struct gs_ctx {
     hipEvent_t ev[GS_EV_RING][GS_STAGE_COUNT + 1] = {}; // ring of per-frame stage brackets (GS_FLAG_TIMING)
     bool have_events = false;
     uint64_t timed_from = 0; // first frame index included in the stage means
+    // frame graph (GS_OPT_FRAME_GRAPH): the frame's launches captured once, replayed with hipGraphLaunch; only the projection's
+    // uniforms change from frame to frame (kernel-node parameter update)
+    bool use_graph = false, graph_valid = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipGraphNode_t pre_node = nullptr;
+    GsPreprocessLaunch pre{};
+    bool gkey_index = false, gkey_tight = false;
+    void* gkey_ext = nullptr;
+    uint64_t graph_frames = 0;
     // frame state
     bool have_frame = false, pending = false, last_debug = false;
     void* last_ext = nullptr;
@@ -172,6 +182,7 @@ static void free_kv(gs_ctx* c) {
 // (key,value) arrays + the control/status block sized for `capacity` entries.
 static int32_t alloc_kv(gs_ctx* c, uint64_t capacity) {
     if (capacity >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "capacity %llu exceeds 2^30 intersections", (unsigned long long)capacity);
+    c->graph_valid = false; // (callers have drained the stream: no replay of the captured frame is in flight)
     free_kv(c);
     capacity = std::max<uint64_t>(capacity, 4096);
     const size_t kb = (size_t)capacity * 4;
@@ -273,6 +284,8 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     c->shadows.clear();
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->gexec) hipGraphExecDestroy(c->gexec);
+    if (c->graph) hipGraphDestroy(c->graph);
     free_kv(c);
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
@@ -292,6 +305,7 @@ static int32_t wait_one(gs_ctx* c);
 GS_EXPORT int32_t gs_wait(gs_ctx* c);
 // Frees the previous scene and per-gaussian work arrays, allocates the work arrays for n gaussians.
 static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity = 0) {
+    c->graph_valid = false;
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
     hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts); hipFree(c->gsort_scratch);
@@ -399,25 +413,13 @@ static inline void mark(gs_ctx* c, int i) { // stage boundary i: closes stage i-
     }
 }
 
-static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8) {
+// Every launch of one frame, in order, on the context's stream (directly, or into a stream capture).
+static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8, bool tight, bool fused) {
     const GsFrame& f = c->frame;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
-    if (c->emit_order == 2) {
-        // auto: the depth-ordered pipeline saves (passes - tile_passes) full sweeps of the instance arrays and the histogram
-        // pass, and costs the gaussian-level counting sort (three small kernels, k_gsort.hip).  Measured at config B: whole
-        // canvas (18.5 M instances) 1.42 vs 1.50 ms, one of 8 slabs (1.9-2.6 M) 418-508 vs 455-566 us, one of 4 slabs 586-699 vs
-        // 618-743 us per frame; below ~1 M instances both are launch-bound and the same.
-        const uint64_t saved = c->passes > c->tile_passes ? c->passes - c->tile_passes : 0;
-        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 1000000ull);
-    } else {
-        c->index_order = (c->emit_order == 1);
-    }
-    // tight (opacity-aware) binning: product frames only; the sub-block mask shares the value word with the gaussian id
-    const bool tight = !debug && c->tile_cull && c->unfused && c->n < (1u << GS_ID_BITS);
-    const bool fused = !debug && c->index_order && !c->unfused;
     if (fused) {
         // experimental (GS_OPT_UNFUSED 0): projection, scan and emission in ONE launch; measured 9 % slower than the three
         // launches at config B (the emission inherits the projection's 4 waves/SIMD and its workgroup granularity)
@@ -425,7 +427,8 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         mark(c, 1);
         mark(c, 2);
     } else {
-        gs_launch_preprocess(c->scene, u, f, c->gdata, c->counts, tight, st);
+        gs_preprocess_prepare(c->pre, c->scene, u, f, c->gdata, c->counts, tight);
+        gs_launch_preprocess(c->pre, st);
         mark(c, 1);
     }
     const uint32_t scan_blocks = (uint32_t)(((size_t)gs_project_emit_blocks(c->n ? c->n : 1) + 1 + 31) & ~(size_t)31);
@@ -476,7 +479,6 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
                                     c->tile_bits, c->tile_passes, c->tile16, st);
     }
     const bool keys16 = !by_index && c->tile16;
-    c->keysG_valid = false;
     if (debug) {
         if (!c->keysU) {
             HIP_TRY(hipMalloc((void**)&c->keysU, (size_t)c->capacity * 4));
@@ -511,6 +513,79 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     if (c->debug_view) gs_launch_debug_view(c->ranges, f, c->debug_view, target, st); // developer views, after the timed stages
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(c->h_sticky, c->sticky, 4 * 4, hipMemcpyDeviceToHost, st));
+    return GS_OK;
+}
+
+static void drop_graph(gs_ctx* c) {
+    if (c->gexec) hipGraphExecDestroy(c->gexec);
+    if (c->graph) hipGraphDestroy(c->graph);
+    c->gexec = nullptr; c->graph = nullptr; c->pre_node = nullptr;
+    c->graph_valid = false;
+}
+
+static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8) {
+    hipStream_t st = c->stream;
+    if (c->emit_order == 2) {
+        // auto: the depth-ordered pipeline saves (passes - tile_passes) full sweeps of the instance arrays and the histogram
+        // pass, and costs the gaussian-level counting sort (three small kernels, k_gsort.hip).  Measured at config B: whole
+        // canvas (18.5 M instances) 1.42 vs 1.50 ms, one of 8 slabs (1.9-2.6 M) 418-508 vs 455-566 us, one of 4 slabs 586-699 vs
+        // 618-743 us per frame; below ~1 M instances both are launch-bound and the same.
+        const uint64_t saved = c->passes > c->tile_passes ? c->passes - c->tile_passes : 0;
+        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 1000000ull);
+    } else {
+        c->index_order = (c->emit_order == 1);
+    }
+    // tight (opacity-aware) binning: product frames only; the sub-block mask shares the value word with the gaussian id
+    const bool tight = !debug && c->tile_cull && c->unfused && c->n < (1u << GS_ID_BITS);
+    const bool fused = !debug && c->index_order && !c->unfused;
+    // GS_OPT_FRAME_GRAPH: replay the captured frame instead of issuing its ~16 commands one by one (frames without per-stage
+    // events or profiler output only).  The capture holds every buffer address and launch geometry of the frame, so anything
+    // that moves a buffer or changes an option drops it (graph_valid); the emission order and the output address are part
+    // of its identity.
+    const bool graphable = c->use_graph && !debug && !c->have_events && !fused && !(c->blend_ablation & 0x10000u) && c->n;
+    if (graphable) {
+        if (!c->gexec || !c->graph_valid || c->gkey_index != c->index_order || c->gkey_tight != tight || c->gkey_ext != ext_rgba8) {
+            drop_graph(c);
+            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight, fused);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc != GS_OK) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess || !g) return fail(GS_ERR_HIP, "frame graph capture: %s", hipGetErrorString(e));
+            c->graph = g;
+            HIP_TRY(hipGraphInstantiate(&c->gexec, g, nullptr, nullptr, 0));
+            size_t nn = 0;
+            HIP_TRY(hipGraphGetNodes(g, nullptr, &nn));
+            std::vector<hipGraphNode_t> nodes(nn);
+            HIP_TRY(hipGraphGetNodes(g, nodes.data(), &nn));
+            uint32_t found = 0;
+            for (hipGraphNode_t nd : nodes) {
+                hipGraphNodeType ty;
+                if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+                hipKernelNodeParams kp;
+                if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == c->pre.func) { c->pre_node = nd; ++found; }
+            }
+            if (found != 1) { // cannot address the projection's node: this frame still runs from the capture, later ones directly
+                c->use_graph = false;
+                c->pre_node = nullptr;
+            }
+            c->gkey_index = c->index_order; c->gkey_tight = tight; c->gkey_ext = ext_rgba8;
+            c->graph_valid = true;
+        } else {
+            c->pre.u = u;
+            hipKernelNodeParams kp{};
+            kp.func = const_cast<void*>(c->pre.func);
+            kp.gridDim = dim3(c->pre.blocks); kp.blockDim = dim3(256); kp.sharedMemBytes = 0;
+            kp.kernelParams = c->pre.args; kp.extra = nullptr;
+            HIP_TRY(hipGraphExecKernelNodeSetParams(c->gexec, c->pre_node, &kp));
+        }
+        HIP_TRY(hipGraphLaunch(c->gexec, st));
+        c->graph_frames++;
+    } else {
+        const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight, fused);
+        if (rc != GS_OK) return rc;
+    }
+    c->keysG_valid = false;
     HIP_TRY(hipGetLastError());
     c->pending = true;
     c->have_frame = true;
@@ -605,6 +680,7 @@ static int32_t add_shadow(gs_ctx* c) {
     if (rc != GS_OK) { gs_destroy(s); return rc; }
     s->emit_order = c->emit_order; s->tile_cull = c->tile_cull; s->unfused = c->unfused; s->debug_view = c->debug_view;
     s->blend_ablation = c->blend_ablation; s->old_gsort = c->old_gsort; s->grid_persist = c->grid_persist; s->timed_from = 0;
+    s->use_graph = c->use_graph;
     c->shadows.push_back(s);
     return GS_OK;
 }
@@ -777,6 +853,8 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* root, gs_stats* out) {
         out->truncated_frames = root->truncated_frames;
         for (gs_ctx* s : root->shadows) out->truncated_frames += s->truncated_frames;
         out->frames_in_flight = (uint32_t)root->shadows.size() + 1u;
+        out->graph_frames = root->graph_frames;
+        for (gs_ctx* s : root->shadows) out->graph_frames += s->graph_frames;
         out->tight_binning = c->last_tight ? 1u : 0u;
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
         if (c->blend_walkers >= 4) { // 8x8-block walkers (4 per 16-tile, 16 per 32-tile): sum over tiles of the deepest walker
@@ -842,7 +920,9 @@ GS_EXPORT int32_t gs_set_option(gs_ctx* c, int32_t key, int64_t value) {
     return rc;
 }
 static int32_t set_option_one(gs_ctx* c, int32_t key, int64_t value) {
+    c->graph_valid = false; // a captured frame holds the options it was recorded with
     switch (key) {
+    case GS_OPT_FRAME_GRAPH: c->use_graph = (value != 0); return GS_OK;
     case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value & 0x3FFFFu; c->old_gsort = ((uint32_t)value & 0x40000u) != 0; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; c->max_I_seen = 0; c->truncated_frames = 0; return GS_OK;

@@ -19,6 +19,7 @@
 // Algorithmic bytes per gaussian: 12 (culled) or 236 (visible) read; 4 (count) + 56 (visible) written.
 // Bound: HBM.  No MFMA (no contraction on this path).
 #include "gs_device.h"
+#include "gs_kernels.h"
 #include "gs_tight.h"
 
 // ---- upload: 320-byte AoS (ply.ts:190-198) -> position planes + 256-byte records ------------------
@@ -513,19 +514,26 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
     hipLaunchKernelGGL(gs_repack_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)d_aos, n, (float*)s.px, (float*)s.py,
                        (float*)s.pz, (float*)s.smax, (float*)s.rec);
 }
-void gs_launch_preprocess(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, bool tight,
-                          hipStream_t st) {
-    if (!f.n) return;
+// The projection's launch as data: the one kernel of a frame whose arguments change from frame to frame (the uniforms, by
+// value), so a captured frame graph (gs_runtime.hip) re-launches it with updated parameters.
+void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
+                           bool tight) {
     // chunks per workgroup (see NB): 8 for a slab narrower than 30 % of the canvas, 4 up to 75 %, else 1
     const uint32_t wcols = f.col1 - f.col0;
     const uint32_t nb = f.full || wcols * 4u > f.ntx * 3u ? 1u : (wcols * 10u > f.ntx * 3u ? 4u : 8u);
-    const uint32_t blocks = (f.n + PRE_G * nb - 1) / (PRE_G * nb);
-#define GS_PRE_LAUNCH(T, NBV)                                                                                                        \
-    hipLaunchKernelGGL((gs_preprocess_kernel<false, T, NBV>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, (uint32_t*)nullptr, \
-                       (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (GsControl*)nullptr)
-    if (tight) { if (nb == 8u) GS_PRE_LAUNCH(true, 8); else if (nb == 4u) GS_PRE_LAUNCH(true, 4); else GS_PRE_LAUNCH(true, 1); }
-    else { if (nb == 8u) GS_PRE_LAUNCH(false, 8); else if (nb == 4u) GS_PRE_LAUNCH(false, 4); else GS_PRE_LAUNCH(false, 1); }
-#undef GS_PRE_LAUNCH
+    L.blocks = (f.n + PRE_G * nb - 1) / (PRE_G * nb);
+    if (tight) L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<false, true, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<false, true, 4>
+                                                                                                : (const void*)&gs_preprocess_kernel<false, true, 1>;
+    else L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<false, false, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<false, false, 4>
+                                                                                              : (const void*)&gs_preprocess_kernel<false, false, 1>;
+    L.s = s; L.u = u; L.f = f; L.gdata = gdata; L.counts = counts;
+    L.keys = nullptr; L.values = nullptr; L.status = nullptr; L.ticket = nullptr; L.ctl = nullptr;
+    L.args[0] = &L.s; L.args[1] = &L.u; L.args[2] = &L.f; L.args[3] = &L.gdata; L.args[4] = &L.counts; L.args[5] = &L.keys;
+    L.args[6] = &L.values; L.args[7] = &L.status; L.args[8] = &L.ticket; L.args[9] = &L.ctl;
+}
+void gs_launch_preprocess(GsPreprocessLaunch& L, hipStream_t st) {
+    if (!L.f.n) return;
+    (void)hipLaunchKernel(L.func, dim3(L.blocks), dim3(256), L.args, 0, st);
 }
 uint32_t gs_project_emit_blocks(uint32_t n) { return (n + PRE_G - 1) / PRE_G; }
 // projection + scan + emission in one launch; status: gs_project_emit_blocks(n) zeroed 8-byte words, ticket: one zeroed word

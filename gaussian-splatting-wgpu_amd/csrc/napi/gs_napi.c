@@ -361,6 +361,7 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
     set_num(env, o, "numEvaluated", (double)st.num_evaluated);
     set_num(env, o, "depthOrdered", (double)st.depth_ordered);
     set_num(env, o, "tightBinning", (double)st.tight_binning);
+    set_num(env, o, "graphFrames", (double)st.graph_frames);
     set_num(env, o, "capacity", (double)st.capacity);
     set_num(env, o, "maxIntersectionsSeen", (double)st.max_intersections_seen);
     set_num(env, o, "truncatedFrames", (double)st.truncated_frames);

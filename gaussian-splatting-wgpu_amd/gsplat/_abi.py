@@ -28,6 +28,7 @@ GS_OPT_UNFUSED = 5
 GS_OPT_DEBUG_VIEW = 6
 GS_OPT_TILE_CULL = 7
 GS_OPT_FRAMES_IN_FLIGHT = 8
+GS_OPT_FRAME_GRAPH = 9
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
@@ -51,7 +52,7 @@ class GsStats(ctypes.Structure):
                 ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float),
                 ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32), ("depth_ordered", ctypes.c_uint32), ("num_evaluated", ctypes.c_uint64),
                 ("capacity", ctypes.c_uint64), ("max_intersections_seen", ctypes.c_uint64), ("truncated_frames", ctypes.c_uint64),
-                ("tight_binning", ctypes.c_uint32), ("frames_in_flight", ctypes.c_uint32)]
+                ("tight_binning", ctypes.c_uint32), ("frames_in_flight", ctypes.c_uint32), ("graph_frames", ctypes.c_uint64)]
 
 
 class GsError(RuntimeError):

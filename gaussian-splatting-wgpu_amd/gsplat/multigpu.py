@@ -89,7 +89,7 @@ class SlabExchange:
         import torch.distributed as dist
         send = self.send if send is None else send
         gathered = self.gathered if gathered is None else gathered
-        if self.world == 1:
+        if self.world == 1 and not getattr(self, "always_collective", False):
             gathered.copy_(send)
         elif self.collective == "gather" and not (dist.get_backend() == "gloo" and send.is_cuda):
             # only the presenting rank needs the slabs (gloo cannot gather device tensors: the rehearsal path below all-gathers)

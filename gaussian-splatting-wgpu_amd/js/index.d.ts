@@ -31,7 +31,7 @@ export class Renderer {
   constructor(canvas: CanvasLike, interactiveCamera: InteractiveCamera, device: number | { ordinal: number; flags?: number; shareWith?: Renderer }, gaussians: PackedGaussians, tileSize: number);
   animate(): Promise<void>; destroy(): Promise<void>;
   renderUniforms(uniforms: Float32Array, debug?: boolean): void; readPixels(): Uint8Array; readBuffer(which: number): ArrayBuffer;
-  stats(): { numGaussians: number; numVisible: number; numIntersections: number; numProcessed: number; numTiles: number; sortPasses: number; frames: number; frameUs: number; stageUs: number[]; numEvaluated: number; depthOrdered: number; tightBinning: number; capacity: number; maxIntersectionsSeen: number; truncatedFrames: number };
+  stats(): { numGaussians: number; numVisible: number; numIntersections: number; numProcessed: number; numTiles: number; sortPasses: number; frames: number; frameUs: number; stageUs: number[]; numEvaluated: number; depthOrdered: number; tightBinning: number; graphFrames: number; capacity: number; maxIntersectionsSeen: number; truncatedFrames: number };
 }
 export function loadFileAsArrayBuffer(path: string): Promise<ArrayBuffer>;
 export function cameraFromJSON(raw: CameraRaw, canvasW: number, canvasH: number): Camera;

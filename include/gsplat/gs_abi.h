@@ -104,6 +104,7 @@ typedef struct gs_stats {
     uint32_t tight_binning;       /* 1 if the last frame used the opacity-aware (tight) binning of the product path: its
                                      instance lists are then a subset of the reference's (GS_OPT_TILE_CULL)             */
     uint32_t frames_in_flight;    /* contexts of the ring gs_render alternates between now (GS_OPT_FRAMES_IN_FLIGHT)      */
+    uint64_t graph_frames;        /* frames replayed from the captured frame graph (GS_OPT_FRAME_GRAPH), summed over the ring */
 } gs_stats;
 
 /* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */
@@ -207,6 +208,13 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     taking turns between them: frame k's blend overlaps frame k+1's binning.  Every frame's result
                                     is what a single context renders; gs_wait waits for all; read-backs, taps and statistics refer
                                     to the LAST frame.  1 = strictly one frame after the other.                                  */
+#define GS_OPT_FRAME_GRAPH 9      /* 1: the frame's commands (1 memset, 12-14 kernels, 2 copies) are captured into a hipGraph the first time
+                                    and replayed with one hipGraphLaunch afterwards; only the projection's uniforms change between
+                                    frames (a kernel-node parameter update).  For hosts bound by launch cost: small scenes (config A:
+                                    a frame is ~70 us of launches) and the narrow slabs of an 8-GPU run.  Frames with per-stage
+                                    events (GS_FLAG_TIMING), gs_render_debug and the profiler taps are issued directly as before;
+                                    the capture is redone when a buffer moves (capacity growth), an option or the emission order
+                                    changes.  Renderer.animate re-encodes every pass every frame (renderer.ts:394-587).  Default 0. */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
 /* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
 int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);

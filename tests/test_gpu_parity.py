@@ -381,6 +381,61 @@ def test_frames_in_flight_match_sequential(oracle):
     seq.destroy()
 
 
+def test_frame_graph_replays_the_same_frames():
+    """GS_OPT_FRAME_GRAPH: frames replayed from the captured hipGraph (uniforms patched into the projection's node) are the
+    frames the directly issued launches give -- moving camera, an option change (re-capture), a capacity regrow on the first
+    frame, a slab writing to a caller's buffer, and the ring of frames in flight."""
+    import torch
+    from gsplat import _abi
+    n, W, H = 60000, 640, 368
+    s = scene(n)
+    us = [_uniforms(W, H, step=k) for k in range(6)]
+    direct = _mk(s, W, H)
+    want = []
+    for u in us:
+        direct.render_uniforms(u); direct.wait()
+        want.append(direct.read_rgba8())
+    g = _mk(s, W, H, max_intersections=4096)  # the first frame overflows: gs_wait grows the arrays and re-renders
+    g.set_option(_abi.GS_OPT_FRAME_GRAPH, 1)
+    g.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)
+    for k, u in enumerate(us):
+        g.render_uniforms(u); g.wait()
+        np.testing.assert_array_equal(g.read_rgba8(), want[k])
+    st = g.stats()
+    assert st["graph_frames"] >= len(us), st["graph_frames"]
+    assert st["num_intersections"] == direct.stats()["num_intersections"]
+    # an option change drops the capture; the next frames come from a new one
+    for r_ in (g, direct):
+        r_.set_option(_abi.GS_OPT_TILE_CULL, 0)
+    direct.render_uniforms(us[2]); direct.wait()
+    g.render_uniforms(us[2]); g.wait()
+    np.testing.assert_array_equal(g.read_rgba8(), direct.read_rgba8())
+    assert g.stats()["tight_binning"] == 0
+    g.set_option(_abi.GS_OPT_TILE_CULL, 1)
+    # frames back to back without a wait, three in flight (the shadows of the ring replay their own captures)
+    g.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 3)
+    before = g.stats()["graph_frames"]
+    for u in us:
+        g.render_uniforms(u)
+    g.wait()
+    np.testing.assert_array_equal(g.read_rgba8(), want[-1])
+    assert g.stats()["graph_frames"] == before + len(us)
+    g.destroy()
+    # a slab on the caller's stream, blending into the caller's buffer
+    c0, c1 = 10, 27
+    stream = torch.cuda.Stream()
+    sl = _mk(s, W, H, cols=(c0, c1), stream=stream.cuda_stream)
+    sl.set_option(_abi.GS_OPT_FRAME_GRAPH, 1)
+    out = torch.zeros((H, (c1 - c0) * 16, 4), dtype=torch.uint8, device="cuda")
+    for k, u in enumerate(us):
+        sl.render_uniforms(u, out_ptr=out.data_ptr())
+    sl.wait()
+    np.testing.assert_array_equal(out.cpu().numpy(), want[-1][:, c0 * 16:c1 * 16])
+    assert sl.stats()["graph_frames"] == len(us)
+    sl.destroy()
+    direct.destroy()
+
+
 import glob as _glob
 import os as _os
 
