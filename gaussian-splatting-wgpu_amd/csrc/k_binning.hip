@@ -155,8 +155,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
     run_nz += s_prefix[1];
     const uint32_t first_nz = run_nz;
     if (vkey) { // ordered compaction of the elements with a non-zero tile count
-        // ... and the digit histograms of the gaussian-level sort that follows (two 5-bit digits of the bucket):
-        // per-workgroup LDS counters, one global atomic per non-empty bin
+        // ... and (round 1's gaussian-level radix sort only, a profiling path now: no ccounts) the digit histograms of the sort
+        // that follows, two 5-bit digits of the bucket: per-workgroup LDS counters, one global atomic per non-empty bin.  The
+        // counting sort of k_gsort.hip builds its own table, and 64 lanes adding into 32 counters serialise: skipped otherwise.
+        const bool want_gh = !ccounts;
         if (tid < 64u) s_gh[tid] = 0u;
         __syncthreads();
         uint32_t roff = run;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
         for (int j = 0; j < SCAN_ITEMS; ++j) {
             if ((v[j] & GS_COUNT_MASK) != 0u) {
                 const uint32_t bucket = v[j] >> GS_COUNT_BITS;
-                vkey[run_nz] = bucket;
+                if (want_gh) vkey[run_nz] = bucket; // (the sort key of the radix path; the count word below carries the bucket too)
                 vval[run_nz] = base + j;
                 if (ccounts) { // the compacted list with its own counts and offsets: what an emission in index order walks
                     ccounts[run_nz] = v[j];
@@ -172,12 +174,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void gs_scan_kernel(const uint32_t* _
                 }
                 ++run_nz;
                 roff += v[j] & GS_COUNT_MASK;
-                atomicAdd(&s_gh[bucket & 31u], 1u);
-                atomicAdd(&s_gh[32u + ((bucket >> 5) & 31u)], 1u);
+                if (want_gh) {
+                    atomicAdd(&s_gh[bucket & 31u], 1u);
+                    atomicAdd(&s_gh[32u + ((bucket >> 5) & 31u)], 1u);
+                }
             }
         }
         __syncthreads();
-        if (tid < 64u && s_gh[tid]) atomicAdd(&ctl->ghist[tid >> 5][tid & 31u], s_gh[tid]);
+        if (want_gh && tid < 64u && s_gh[tid]) atomicAdd(&ctl->ghist[tid >> 5][tid & 31u], s_gh[tid]);
     }
     if (chunk_table) { // (with ccounts: positions in the compacted list, otherwise element indices)
         uint32_t r2 = run, knz = first_nz;
