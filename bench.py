@@ -451,8 +451,16 @@ def main():
     if multi:
         # whole-frame statistics are the sums over the slabs
         v = torch.tensor([st["num_visible"], st["num_intersections"], st["num_processed"]], dtype=torch.int64, device=dev)
+        per = torch.zeros((world, 3), dtype=torch.int64, device=dev)
+        per[rank] = v
+        dist.all_reduce(per)  # (one row per rank; a sum of one-hot rows is a gather every backend has)
         dist.all_reduce(v)
         tot_vis, tot_I, tot_Ip = (int(x) for x in v.tolist())
+        per_rank = [{"rank": g, "columns": [bounds[g], bounds[g + 1]], "visible": int(per[g][0]), "intersections": int(per[g][1])} for g in range(world)]
+        tr = torch.tensor([1 if trouble else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        if int(tr.item()) and not trouble:
+            trouble["truncated"] = "a rank other than 0 rendered frames from truncated lists"
     else:
         tot_vis, tot_I, tot_Ip = st["num_visible"], st["num_intersections"], st["num_processed"]
 
@@ -474,6 +482,8 @@ def main():
                        "tight_binning": bool(st["tight_binning"]), "blend_mode": "exact" if args.exact else "fused",
                        "camera": "64-step orbit, moved every frame"},
         }
+        if multi:
+            line["per_rank"] = per_rank
         if verified is not None:
             line["slab_frame_equals_single_gpu_frame"] = verified
             line["every_rank_slab_equals_its_columns_of_the_single_gpu_frame"] = slabs_ok

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-rank THROUGHPUT of an N-GPU slab with K frames in flight (K contexts sharing the splats, each on its own stream),
 measured on one GPU: what one rank of an N-GPU run can sustain when its frames overlap.  No collective here.
-Usage: slab_flight_probe.py [world=8] [K=3] [config=B|C] [emit_order=2]"""
+Usage: slab_flight_probe.py [world=8] [K=3] [config=B|C] [emit_order=2] [balanced=1] [ranks=ends|all]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-wgpu_amd")); sys.path.insert(0, ROOT)
@@ -12,13 +12,27 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 cfgname = sys.argv[3] if len(sys.argv) > 3 else "B"
 order = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+balanced = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+which = sys.argv[6] if len(sys.argv) > 6 else "ends"
 N = 6_100_000
 W, H = (1920, 1080) if cfgname == "B" else (3840, 2160)
 sp = synth.bicycle_like_torch(N, synth.BASE_SEED + (1 if cfgname == "B" else 2), "cuda")
 pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians); pg.numGaussians, pg.gaussiansBuffer = N, sp
 b = multigpu.slab_bounds(W, 16, world)
 us = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
-for rank in sorted({0, world // 2, world - 1}):
+if balanced and world > 1:  # as bench.py does: instances per tile column over 8 cameras of the orbit, from whole-canvas frames
+    import numpy as np
+    full = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, 16)
+    ntx = multigpu.num_tile_columns(W, 16)
+    col = np.zeros(ntx)
+    for k in range(0, 64, 8):
+        full.render_uniforms(us[k]); full.wait()
+        tc = np.diff(np.concatenate([[0], full.read_buffer(_abi.GS_BUF_RANGES).astype(np.int64)])).astype(np.float64)
+        col += tc[: (tc.size // ntx) * ntx].reshape(-1, ntx).sum(axis=0)
+    b = multigpu.balanced_bounds(col, world)
+    full.destroy()
+print("bounds", b, flush=True)
+for rank in (range(world) if which == "all" else sorted({0, world // 2, world - 1})):
     cols = (b[rank], b[rank + 1]) if world > 1 else None
     streams = [torch.cuda.Stream() for _ in range(K)]
     rs = []
