@@ -489,7 +489,7 @@ def main():
             line["every_rank_slab_equals_its_columns_of_the_single_gpu_frame"] = slabs_ok
         stq, stage_source = st, "the timed region"
         if not multi and st["frames_in_flight"] > 1 and not args.no_timing:
-            # the timed region kept two frames in flight: the kernels of consecutive frames overlap there and stretch each other, so
+            # the timed region kept several frames in flight: the kernels of consecutive frames overlap there and stretch each other, so
             # a stage's hipEvent bracket is not a kernel duration any more.  The same steps are run once more, outside the timed
             # region, strictly one frame after the other: its per-stage times (and the frames/s of that discipline) are what
             # `stages` and `roofline` are computed from; the overlapped brackets are kept as `stages_overlapped_us`.

@@ -188,7 +188,7 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     0: depth-ordered pipeline: sort the visible GAUSSIANS by depth bucket, emit their instances
                                     in that order (work-balanced), sort the instances by tile only (2 digits);
                                     2 (default): choose per frame from the previous frame's instance count ((radix sweeps saved)
-                                    x instances >= 15 M -> 0, else 1).  Sorted keys/values, ranges and image are identical in
+                                    x instances >= 1 M -> 0, else 1).  Sorted keys/values, ranges and image are identical in
                                     every mode.                                                                           */
 #define GS_OPT_DEBUG_VIEW 6      /* the developer views commented out in compute_tiles.wgsl:35-38,67-70, drawn over the frame: 0 off,
                                     1 tile borders (last row/column of every tile red), 2 list length/1000 as grey, 3 pixel
