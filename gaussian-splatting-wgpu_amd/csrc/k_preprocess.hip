@@ -111,7 +111,11 @@ __device__ __forceinline__ void sh_colour(const float4* __restrict__ rec, float 
     float shv[48];
 #pragma unroll
     for (int p = 0; p < 12; ++p) {
+#ifdef PRE_ABLATE_SH
+        const float4 vv = make_float4(X, Y, Z, 0.5f); // PROFILING BUILD ONLY: no SH reads
+#else
         const float4 vv = rec[2 + p];
+#endif
         shv[4 * p + 0] = vv.x; shv[4 * p + 1] = vv.y; shv[4 * p + 2] = vv.z; shv[4 * p + 3] = vv.w;
     }
 #pragma unroll
@@ -377,6 +381,9 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             for (int k = 0; k < 4; ++k) { if (k < (int)w) wbase += s_tw[k]; R += s_tw[k]; }
             s_trp[tid] = wbase + rincl - nrows;
             __syncthreads();
+#ifdef PRE_ABLATE_ROWS
+            if (R > 0x7FFFFFFFu) // PROFILING BUILD ONLY: the per-row tight count is skipped
+#endif
             for (uint32_t ri = tid; ri < R; ri += 256) {
                 uint32_t j = 0; // largest j with rp[j] <= ri (row-less survivors share their successor's prefix)
 #pragma unroll
