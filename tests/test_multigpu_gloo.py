@@ -255,3 +255,52 @@ def test_pipelined_slabs_on_one_gpu(tmp_path, K):
     mp.spawn(_gpu_pipeline_worker, args=(2, port, 640, 368, 16, out, K), nprocs=2, join=True)
     ok = np.load(out)
     assert ok[0] == 1, "the assembled last frame differs from the whole-canvas frame"
+
+
+def _gpu_rccl_worker(rank, world, port, W, H, ts, out, collective):
+    """The N > 1 step over RCCL itself with a world of one rank (a one-GPU box cannot hold two RCCL ranks): the collective
+    is really called on the communication stream (always_collective), three slab contexts in flight."""
+    import torch
+    import torch.distributed as dist
+    import gsplat
+    from gsplat import multigpu, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    s = synth.bicycle_like(60000)
+    us = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(8)]
+    pg = gsplat.PackedGaussians(s)
+    owner = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts)
+    tb = torch.tensor(multigpu.slab_bounds(W, ts, 1), dtype=torch.int64, device=dev)
+    dist.broadcast(tb, src=0)
+    x = multigpu.SlabExchange(W, H, ts, 1, 0, dev, bounds=[int(v) for v in tb.tolist()], collective=collective)
+    x.always_collective = True
+    mk = lambda stream, share: gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts, cols=x.cols, stream=stream, share_with=share)
+    pipe = multigpu.PipelinedSlabs(x, mk, 3, owner=owner)
+    for u in us:
+        pipe.submit(u)
+    pipe.finish()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    owner.render_uniforms(us[-1])
+    owner.wait()
+    ok = int(np.array_equal(x.image.cpu().numpy(), owner.read_rgba8()))
+    t = torch.tensor([ok], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    np.save(out, np.array([int(t.item())]))
+    pipe.destroy()
+    owner.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("collective", ["gather", "all_gather"])
+def test_pipelined_slabs_over_rccl_world_of_one(tmp_path, collective):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + 40 + len(collective)
+    mp.spawn(_gpu_rccl_worker, args=(1, port, 640, 368, 16, out, collective), nprocs=1, join=True)
+    assert np.load(out)[0] == 1, "the frame gathered and assembled over RCCL differs from the whole-canvas frame"
