@@ -16,7 +16,9 @@
 // All three are HBM-trivial (10-40 MB); what they cost is their dependent launches.
 #include "gs_device.h"
 
-#define GT_ITEMS 16
+#ifndef GT_ITEMS
+#define GT_ITEMS 20 // 5120 per tile: config B's 2.43 M visible gaussians are 475 tiles = ONE residency round at two workgroups per CU
+#endif              // (16: 594 tiles, two rounds, scatter 42 us)
 #define GT_THREADS 256
 #define GT (GT_THREADS * GT_ITEMS) // visible gaussians per tile
 #define GBINS 1024                 // bucket = u32(min(50 depth, 999)) < 1000 (write_tile_ids.wgsl:31)
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(GT_THREADS) void gs_gsort_rowscan_kernel(uint2* __r
 struct GsortShared {
     uint2 base[GBINS];                 // first sorted position / first instance offset of (bucket, this tile)
     uint32_t binstart[GBINS];          // first slot of the bucket in the tile's sorted order
-    uint32_t whist[GT_THREADS / 64][GBINS]; // per-wave running counts while ranking; then the prefix of the sorted tile counts
+    uint32_t whist[(GT > (GT_THREADS / 64) * GBINS ? GT : (GT_THREADS / 64) * GBINS) / GBINS][GBINS]; // per-wave running counts while ranking ([wave][bucket]); then the prefix of the sorted tile counts (GT words)
     uint32_t id[GT], word[GT];
     uint2 w2[4];
 };
