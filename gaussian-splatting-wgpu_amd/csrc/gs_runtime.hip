@@ -416,6 +416,10 @@ static inline void mark(gs_ctx* c, int i) { // stage boundary i: closes stage i-
 // Every launch of one frame, in order, on the context's stream (directly, or into a stream capture).
 static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8, bool tight, bool fused) {
     const GsFrame& f = c->frame;
+    // tight emission: 4 workgroups per CU, all resident at once (5 fit), static chunk split.  Config B: 768 workgroups 206 us,
+    // 1024: 171, 1280: 219 (18 056 chunks on 5 120 waves = 3.5 rounds of chunks), 1536: 193, 2048: 180; drawing the chunks from
+    // 64 ticket words instead: 195-200.
+    const uint32_t emit_grid = c->grid_persist;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
@@ -472,7 +476,7 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
         }
         mark(c, 2);
         if (tight)
-            gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
+            gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, emit_grid,
                                  c->tile_bits, c->tile_passes, c->tile16, /*by_index=*/false, st);
         else
             gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
