@@ -506,10 +506,10 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         // loaded registers into the operand tuples of the LDS stores / packed multiplies right behind the loads, and the
         // s_waitcnt that copy needs turns the prefetch into a blocking gather (seen in the ISA of every build before this one).
         asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2));
+        const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
+        const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
+        const float op = __uint_as_float(r2.w);
         if (lane < cnt && (!MASKED || ((vcur >> mybit) & 1u))) {
-            const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
-            const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
-            const float op = __uint_as_float(r2.w);
             const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
             const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
             if (QCULL) {
@@ -521,20 +521,25 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 rel = !(dbg & 1u); // the emission already decided it for exactly these 64 pixels
             }
             npd = rel && !pd;
-            if (rel) { // only surviving entries are parked for the broadcast
-                const float L = 1.44269502162933349609375f;
-                // LDS reads are priced by width (ds_read_b64 2 cycles, b128 4, b96 8 - the loop is LDS-array bound as much as
-                // VALU bound), so the fused layout is two full float4 and one float: (x, y, r, g) (conic', log2 op) (b).
-                // The opacity rides in the exponent: alpha = exp2(power*log2(e) + log2(op)).
-                if (EXACT) {
-                    sP0[lane] = make_float4(gxp, gyp, 0.0f, 0.0f);
-                    sP1[lane] = make_float4(cx, cy, cz, 0.0f);
-                    sP2[lane] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
-                } else {
-                    sP0[lane] = make_float4(gxp, gyp, __uint_as_float(r2.x), __uint_as_float(r2.y));
-                    sP1[lane] = make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, __builtin_amdgcn_logf(op));
-                    sP2[lane].x = __uint_as_float(r2.z); // 16-byte stride: one address register serves all three reads
-                }
+        }
+        // only surviving entries are parked for the broadcast, DENSELY (slot = rank among the survivors, list order kept): the
+        // evaluation loop then walks slots 0, 1, 2 ... with immediate LDS offsets, four per trip, instead of deriving an address
+        // from a bit scan for every entry (one VALU move per evaluation in a loop that runs at the VALU issue rate)
+        const unsigned long long m = __ballot(rel);
+        if (rel) {
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const float L = 1.44269502162933349609375f;
+            // LDS reads are priced by width (ds_read_b64 2 cycles, b128 4, b96 8 - the loop is LDS-array bound as much as
+            // VALU bound), so the fused layout is two full float4 and one float: (x, y, r, g) (conic', log2 op) (b).
+            // The opacity rides in the exponent: alpha = exp2(power*log2(e) + log2(op)).
+            if (EXACT) {
+                sP0[slot] = make_float4(gxp, gyp, 0.0f, 0.0f);
+                sP1[slot] = make_float4(cx, cy, cz, 0.0f);
+                sP2[slot] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
+            } else {
+                sP0[slot] = make_float4(gxp, gyp, __uint_as_float(r2.x), __uint_as_float(r2.y));
+                sP1[slot] = make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, __builtin_amdgcn_logf(op));
+                sP2[slot].x = __uint_as_float(r2.z); // 16-byte stride: one address register serves all three reads
             }
         }
         const uint32_t nb = bb + 64;
@@ -545,17 +550,15 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        unsigned long long m = __ballot(rel);
-        evaluated += (uint32_t)__popcll(m);
+        const uint32_t nrel = (uint32_t)__popcll(m);
+        evaluated += nrel;
         // The reference skips an entry whose power is > 0; for a positive-definite conic the power cannot be (beyond
         // rounding, which the oracle's ill-conditioning margin covers), so the fused loop only pays for that compare in
         // a batch that holds a survivor with a non-positive-definite conic (never produced by the projection's +0.3
         // low-pass; NaN records land here too).
         auto walk = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
-            while (m) {
-                const uint32_t e = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1ull;
+            auto one = [&](uint32_t e) {
                 const float4 p0 = sP0[e];
                 const float4 p1 = sP1[e];
                 const float dx = p0.x - pxf, dy = p0.y - pyf;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                         // Same operations on the kept lanes, nothing on the others: the frame does not change by a bit.
                         float wgt;
                         unsigned long long save;
-                        asm volatile(
+                        asm(
                             "s_mov_b64 %[save], exec\n\t"
                             "v_cmpx_le_f32_e32 vcc, %[c255], %[alpha]\n\t"
                             "v_cmpx_le_f32_e32 vcc, %[thr], %[test]\n\t"
@@ -609,7 +612,10 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                             : "vcc");
                     }
                 }
-            }
+            };
+            uint32_t e = 0;
+            for (; e + 4u <= nrel; e += 4u) { one(e); one(e + 1u); one(e + 2u); one(e + 3u); }
+            for (; e < nrel; ++e) one(e);
         };
         if (EXACT || __ballot(npd) != 0ull) walk(std::true_type{});
         else walk(std::false_type{});
