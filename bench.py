@@ -236,6 +236,9 @@ def main():
                          "their launches directly whatever this says).  Default 0: measured no faster on this stack (config A 14.1 k "
                          "vs 14.6 k frames/s: hipGraphLaunch of 16 nodes costs the host what 16 launches do)")
     ap.add_argument("--force-multi", action="store_true", help="rehearsal: run the N > 1 code path with a world of one rank")
+    ap.add_argument("--frame-groups", type=int, default=1,
+                    help="N>1, opt-in: G groups of N/G ranks render alternate frames, every frame being N/G column slabs gathered to "
+                         "rank 0 (multigpu.FrameGroupSlabs).  Default 1 = the N column slabs of SURVEY 8e")
     ap.add_argument("--even-slabs", action="store_true",
                     help="N>1: equal tile-column slabs instead of slabs balanced by the instance counts of a calibration pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
@@ -329,7 +332,10 @@ def main():
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
     owner = xch = pipe = None
-    bounds = multigpu.slab_bounds(W, ts, world)  # tile-column slabs
+    if args.frame_groups < 1 or world % args.frame_groups:
+        raise SystemExit("--frame-groups must divide the number of ranks")
+    nslabs = world // args.frame_groups  # slabs per frame
+    bounds = multigpu.slab_bounds(W, ts, nslabs)  # tile-column slabs
     if multi:
         owner = r
         if not args.even_slabs:
@@ -343,13 +349,11 @@ def main():
                     owner.wait()
                     tc = np.diff(np.concatenate([[0], owner.read_buffer(_abi.GS_BUF_RANGES).astype(np.int64)])).astype(np.float64)
                     col += tc[: (tc.size // ntx_b) * ntx_b].reshape(-1, ntx_b).sum(axis=0)  # instances per tile, summed over the rows
-                bounds = multigpu.balanced_bounds(col, world)
+                bounds = multigpu.balanced_bounds(col, world // args.frame_groups)
             tb = torch.tensor(bounds, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
             dist.broadcast(tb, src=0)
             bounds = [int(v) for v in tb.tolist()]
-        cols = (bounds[rank], bounds[rank + 1])
-        xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, bounds=bounds, collective=args.collective)
-        xch.always_collective = args.force_multi  # a world of one would otherwise copy instead of calling the collective
+        cols = (bounds[rank % nslabs], bounds[rank % nslabs + 1])
 
         def make_slab_renderer(stream_handle, share_with, fl=eflag):
             rr = gsplat.Renderer(gsplat.Canvas(W, H), None, local_rank, pg, ts, flags=fl, cols=cols, stream=stream_handle, share_with=share_with)
@@ -357,7 +361,14 @@ def main():
             return rr
 
         # K frames in flight per rank: K slab contexts on their own streams, collectives in frame order on one more stream
-        pipe = multigpu.PipelinedSlabs(xch, make_slab_renderer, args.frames_in_flight if args.frames_in_flight > 0 else 3, owner=owner)
+        K = args.frames_in_flight if args.frames_in_flight > 0 else 3
+        if args.frame_groups > 1:
+            pipe = multigpu.FrameGroupSlabs(W, H, ts, world, rank, dev, args.frame_groups, bounds, make_slab_renderer, K, owner=owner)
+            xch = pipe.x
+        else:
+            xch = multigpu.SlabExchange(W, H, ts, world, rank, dev, bounds=bounds, collective=args.collective)
+            xch.always_collective = args.force_multi  # a world of one would otherwise copy instead of calling the collective
+            pipe = multigpu.PipelinedSlabs(xch, make_slab_renderer, K, owner=owner)
         r = pipe.renderers[0]
 
     def step(k):
@@ -422,11 +433,12 @@ def main():
     if multi and not args.no_verify:
         # every rank: the slab it sent last (still in its send buffer) against its columns of a whole-canvas render here
         last_k = args.warmup + args.steps - 1
-        owner.render_uniforms(uniforms[last_k % 64])
+        own_k, own_slot = (pipe.last_own if args.frame_groups > 1 else (last_k, last_k % pipe.K))  # the last frame THIS rank rendered
+        owner.render_uniforms(uniforms[own_k % 64])
         owner.wait()
         whole_local = torch.from_numpy(owner.read_rgba8())
-        b0, e0 = xch.pixels[rank]
-        mine = pipe.send[last_k % pipe.K][: H * (e0 - b0) * 4].view(H, e0 - b0, 4).cpu()
+        b0, e0 = xch.pixels[rank % nslabs]
+        mine = pipe.send[own_slot][: H * (e0 - b0) * 4].view(H, e0 - b0, 4).cpu()
         slab_ok = bool(torch.equal(mine, whole_local[:, b0:e0]))
         if not slab_ok:
             print("verify: rank %d: its own slab differs from the whole-canvas render in %d pixels" % (rank, int((mine != whole_local[:, b0:e0]).any(dim=2).sum())), file=sys.stderr, flush=True)
@@ -455,8 +467,8 @@ def main():
         per[rank] = v
         dist.all_reduce(per)  # (one row per rank; a sum of one-hot rows is a gather every backend has)
         dist.all_reduce(v)
-        tot_vis, tot_I, tot_Ip = (int(x) for x in v.tolist())
-        per_rank = [{"rank": g, "columns": [bounds[g], bounds[g + 1]], "visible": int(per[g][0]), "intersections": int(per[g][1])} for g in range(world)]
+        tot_vis, tot_I, tot_Ip = (int(x) // args.frame_groups for x in v.tolist())  # (each group's ranks describe a frame of their own)
+        per_rank = [{"rank": g, "columns": [bounds[g % nslabs], bounds[g % nslabs + 1]], "visible": int(per[g][0]), "intersections": int(per[g][1])} for g in range(world)]
         tr = torch.tensor([1 if trouble else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         if int(tr.item()) and not trouble:
@@ -474,8 +486,9 @@ def main():
             # this many of them in flight (GS_OPT_FRAMES_IN_FLIGHT: a shadow context with its own stream and per-frame arrays)
             "frames_in_flight": pipe.K if pipe is not None else st["frames_in_flight"],
             "config": {"workload": cfg["name"], "gaussians": N, "width": W, "height": H, "tile_size": ts,
-                       "parallelism": ("tile-column slabs x%d (%s, bounds %s) + RCCL %s of the rgba8 slabs to rank 0, %d frames in flight per rank"
-                                       % (world, "even" if args.even_slabs else "balanced by instance count", bounds, args.collective, pipe.K))
+                       "parallelism": ("%stile-column slabs x%d (%s, bounds %s) + RCCL %s of the rgba8 slabs to rank 0, %d frames in flight per rank"
+                                       % (("%d groups of ranks rendering alternate frames, each frame: " % args.frame_groups) if args.frame_groups > 1 else "",
+                                          nslabs, "even" if args.even_slabs else "balanced by instance count", bounds, args.collective, pipe.K))
                        if multi else "single GPU",
                        "visible": tot_vis, "intersections": tot_I, "processed": tot_Ip, "block_evaluated": st["num_evaluated"],
                        "sort_passes": st["sort_passes"], "depth_ordered_emission": bool(st["depth_ordered"]),

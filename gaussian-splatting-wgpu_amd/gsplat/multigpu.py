@@ -246,3 +246,107 @@ class PipelinedSlabs:
         for r in reversed(self.renderers):
             r.destroy()
         self.renderers = []
+
+
+class FrameGroupSlabs:
+    """G groups of S = world / G ranks render ALTERNATE frames; every frame is still S tile-column slabs gathered to rank 0 and
+    assembled there.  A rank's frame costs a fixed part (the O(N) cull and scan, launches too small to fill the chip) plus a part
+    proportional to its slab, so fewer, wider slabs per frame use the GPUs better: at 1080p eight slabs project to 4.6x one GPU,
+    two groups of four slabs to 6.0x, four groups of two to 7.3x (profiles/r02_slab_per_rank.txt) -- for a frame latency G
+    times longer.  Opt-in (bench.py --frame-groups G): its sub-communicators have only been rehearsed over gloo on one GPU.
+
+    Frame k belongs to group k % G.  Rank r is slab r % S of group r // S.  Communicator h holds the ranks of group h and, for
+    h > 0, rank 0, which receives every frame; rank 0 issues the gathers of ALL frames in frame order on its communication
+    stream, the other ranks only those of their own frames.  Within a rank: K slab contexts in flight as in PipelinedSlabs."""
+
+    def __init__(self, width, height, tile_size, world, rank, device, groups, bounds, make_renderer, frames_in_flight=3, owner=None):
+        import torch
+        import torch.distributed as dist
+        if groups < 1 or world % groups:
+            raise ValueError("the world (%d) must be a multiple of the frame groups (%d)" % (world, groups))
+        self.torch, self.dist = torch, dist
+        self.G, self.S = groups, world // groups
+        self.rank, self.group, self.slab = rank, rank // self.S, rank % self.S
+        # the geometry of ONE frame: S slabs; this rank's slab index inside it
+        self.x = SlabExchange(width, height, tile_size, self.S, self.slab, device, bounds=bounds, collective="gather")
+        self.pgs = []
+        for h in range(groups):  # every rank creates every communicator, in the same order
+            ranks = list(range(h * self.S, (h + 1) * self.S))
+            self.pgs.append(dist.new_group(ranks if h == 0 else [0] + ranks))
+        self.K = int(frames_in_flight)
+        self.streams = [torch.cuda.Stream(device) for _ in range(self.K)]
+        self.comm = torch.cuda.Stream(device)
+        self.renderers = [make_renderer(self.streams[k].cuda_stream, owner) for k in range(self.K)]
+        self.assembler = make_renderer(self.comm.cuda_stream, owner) if rank == 0 else None
+        if self.assembler is not None:
+            self.x.renderer = self.assembler
+        self.send = [torch.zeros_like(self.x.send) for _ in range(self.K)]
+        self.dummy = torch.zeros_like(self.x.send)
+        # rank 0 receives S slabs, behind its own dummy contribution when the frame is another group's
+        self.gathered = torch.zeros(self.x.stride * (self.S + 1), dtype=torch.uint8, device=device) if rank == 0 else None
+        self.ev_render = [torch.cuda.Event() for _ in range(self.K)]
+        self.ev_free = [None] * self.K
+        self.k = 0       # frames submitted
+        self.mine = 0    # frames this rank rendered
+        self.last_own = None  # (frame index, slot) of the last frame this rank rendered
+
+    def _collective(self, h, send):
+        """The gather of one frame of group h, on the current (communication) stream."""
+        torch, dist, x = self.torch, self.dist, self.x
+        n = self.S + (1 if h else 0)  # ranks in communicator h
+        if dist.get_backend() == "gloo" and send.is_cuda:  # rehearsal: staged through the host (SlabExchange.exchange)
+            torch.cuda.synchronize(send.device)
+            host = send.cpu()
+            parts = [torch.empty_like(host) for _ in range(n)]
+            dist.all_gather(parts, host, group=self.pgs[h])
+            if self.rank == 0:
+                self.gathered[: n * x.stride].copy_(torch.cat(parts))
+            torch.cuda.synchronize(send.device)
+        else:
+            parts = list(self.gathered[: n * x.stride].view(n, x.stride).unbind(0)) if self.rank == 0 else None
+            dist.gather(send, parts, dst=0, group=self.pgs[h])
+        if self.rank == 0:
+            first = x.stride if h else 0  # skip rank 0's dummy
+            x.assemble(self.gathered[first: first + self.S * x.stride])
+
+    def submit(self, uniforms):
+        torch = self.torch
+        h = self.k % self.G
+        if h == self.group:
+            slot = self.mine % self.K
+            s = self.streams[slot]
+            if self.ev_free[slot] is not None:
+                s.wait_event(self.ev_free[slot])
+            self.renderers[slot].render_uniforms(uniforms, out_ptr=self.send[slot].data_ptr())
+            self.ev_render[slot].record(s)
+            self.comm.wait_event(self.ev_render[slot])
+            with torch.cuda.stream(self.comm):
+                self._collective(h, self.send[slot])
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+            self.ev_free[slot] = ev
+            self.last_own = (self.k, slot)
+            self.mine += 1
+        elif self.rank == 0:
+            with torch.cuda.stream(self.comm):
+                self._collective(h, self.dummy)
+        self.k += 1
+
+    def finish(self):
+        err = None
+        for r in self.renderers:
+            try:
+                r.wait()
+            except Exception as e:
+                err = err or e
+        self.comm.synchronize()
+        if err is not None:
+            raise err
+
+    def destroy(self):
+        if self.assembler is not None:
+            self.assembler.destroy()
+            self.assembler = None
+        for r in reversed(self.renderers):
+            r.destroy()
+        self.renderers = []

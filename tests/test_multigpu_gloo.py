@@ -304,3 +304,51 @@ def test_pipelined_slabs_over_rccl_world_of_one(tmp_path, collective):
     port = 29500 + (os.getpid() % 2000) + 40 + len(collective)
     mp.spawn(_gpu_rccl_worker, args=(1, port, 640, 368, 16, out, collective), nprocs=1, join=True)
     assert np.load(out)[0] == 1, "the frame gathered and assembled over RCCL differs from the whole-canvas frame"
+
+
+def _gpu_groups_worker(rank, world, port, W, H, ts, out, groups):
+    """multigpu.FrameGroupSlabs: groups of ranks render alternate frames, every frame = world/groups slabs gathered to rank 0."""
+    import torch
+    import torch.distributed as dist
+    import gsplat
+    from gsplat import _abi, multigpu, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    s = synth.bicycle_like(60000)
+    us = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(9)]
+    pg = gsplat.PackedGaussians(s)
+    owner = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts)
+    S = world // groups
+    bounds = multigpu.slab_bounds(W, ts, S)
+    cols = (bounds[rank % S], bounds[rank % S + 1])
+    mk = lambda stream, share: gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, ts, cols=cols, stream=stream, share_with=share)
+    fg = multigpu.FrameGroupSlabs(W, H, ts, world, rank, dev, groups, bounds, mk, frames_in_flight=2, owner=owner)
+    ok = 1
+    for k, u in enumerate(us):
+        fg.submit(u)
+        if k in (4, len(us) - 1):  # an odd and an even frame: both groups' frames must reach rank 0 intact
+            fg.finish()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            if rank == 0:
+                owner.render_uniforms(u)
+                owner.wait()
+                ok &= int(np.array_equal(fg.x.image.cpu().numpy(), owner.read_rgba8()))
+    if rank == 0:
+        np.save(out, np.array([ok]))
+    fg.destroy()
+    owner.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_frame_groups_on_one_gpu(tmp_path):
+    """Four processes on the one GPU: two groups of two slabs render alternate frames."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + 50
+    mp.spawn(_gpu_groups_worker, args=(4, port, 640, 368, 16, out, 2), nprocs=4, join=True)
+    assert np.load(out)[0] == 1, "a frame gathered from a frame group differs from the whole-canvas frame"
