@@ -178,6 +178,8 @@ def self_check(gsplat, _abi, r, W, H, ts, device, u_last, args):
     o.render_uniforms(u_last)
     o.wait()
     ref_binning_same = bool(np.array_equal(o.read_rgba8(), other_img))
+    stref = o.stats()  # the reference's binning of the same camera: its instance and staged-entry counts
+    _KEEP["reference_binning"] = {"intersections": stref["num_intersections"], "processed": stref["num_processed"]}
     o.destroy()
     d = np.abs(exact_img[..., :3].astype(np.int32) - fused_img[..., :3].astype(np.int32)).max(axis=2)
     detail = {"fused_vs_exact_pixels_off_by_more_than_1_lsb": int((d > 1).sum()), "fused_vs_exact_max_lsb": int(d.max()),
@@ -553,6 +555,16 @@ def main():
             line["invalid_reason"] = trouble.get("truncated", "truncated frames")
         if not multi and not args.no_verify:
             line.update(self_check(gsplat, _abi, r, W, H, ts, local_rank, uniforms[(args.warmup + args.steps - 1) % 64], args))
+            rb = _KEEP.get("reference_binning")
+            if rb and "roofline" in line and line["roofline"]["kernel"] == "blend" and line["config"]["tight_binning"]:
+                # SURVEY 8(d)'s figure for the blend is 40 B per staged entry of the REFERENCE's lists; the tight binning of the product
+                # path removes the entries the reference would stage and skip, so `achieved` (the bytes of the lists this build really
+                # walks) fell although the kernel got faster.  The same launch time against the reference's lists for the last camera:
+                ref_bytes = 40 * rb["processed"] + 4 * W * H
+                ach = ref_bytes / (line["roofline"]["launch_us"] * 1e-6) / 1e9
+                line["roofline"]["reference_equivalent"] = {"alg_bytes": int(ref_bytes), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                                                            "staged_entries_reference_binning": rb["processed"], "intersections_reference_binning": rb["intersections"],
+                                                            "note": "SURVEY 8(d) bytes of the reference's lists for the last camera / this build's launch time"}
         if not multi and not args.no_cpu:
             u_last = uniforms[(args.warmup + args.steps - 1) % 64]
             line["cpu_baseline"], ref = cpu_baseline(host_scene, N, W, H, ts, u_last, args.cpu_max)
