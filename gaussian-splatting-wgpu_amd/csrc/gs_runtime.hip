@@ -549,6 +549,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
     const bool graphable = c->use_graph && !debug && !c->have_events && !fused && !(c->blend_ablation & 0x10000u) && c->n;
     if (graphable) {
         if (!c->gexec || !c->graph_valid || c->gkey_index != c->index_order || c->gkey_tight != tight || c->gkey_ext != ext_rgba8) {
+            if (c->gexec) HIP_TRY(hipStreamSynchronize(st)); // a replay of the old capture may still be running: not destroyed under it
             drop_graph(c);
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
             const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight, fused);
