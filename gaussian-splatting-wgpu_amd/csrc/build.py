@@ -17,7 +17,7 @@ ARCH = "gfx950"
 # loads): projection 282 -> 243 us, blend 738 -> 712 us with the flag (profiles/README.md).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
-SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_gsort.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
+SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_gsort.hip", "k_rows.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
 
 
 def _stale(target, deps):

@@ -19,6 +19,7 @@ struct GsFrame {
     uint32_t px0, slab_w;// first pixel column and pixel width of the slab
     uint32_t capacity;   // entries the (key,value) arrays can hold
     uint32_t full;       // col0==0 && col1==ntx
+    uint32_t row_cap;    // row-item slots the arena / the row-sorted array can hold (a multiple of 16: tight row pipeline)
 };
 
 // ---- device-resident control block (zeroed by one memset per frame) -----------------------------
@@ -28,27 +29,35 @@ struct GsFrame {
 #define GS_COUNT_MASK 0x3FFFFFu
 
 struct GsControl {
-    uint32_t scan_ticket[2];  // dynamic block ids: [0] tile-count scan in index order, [1] in depth order
+    uint32_t scan_ticket[2];  // dynamic block ids of the tile-count scan (index-order pipeline)
     uint32_t sort_ticket[4];  // dynamic tile ids, one per radix pass of the instance sort
-    uint32_t gsort_ticket[2]; // ... of the gaussian-level sort by depth bucket
-    uint32_t pe_ticket;       // ... of the fused projection+scan+emission kernel
+    uint32_t rows_ticket;     // ... of the row sort (k_rows.hip)
+    uint32_t num_slots;       // row-item slots of the frame in depth order (written by the gaussian-level sort)
+    uint32_t num_items;       // row items of the frame (slots that are not holes; written by the expansion)
     uint32_t fault;           // set when a bounded spin gives up
-    uint32_t overflow;        // set when I exceeds capacity
-    uint32_t num_intersections; // I (written by the scan's last block)
+    uint32_t overflow;        // set when I exceeds capacity, or the row items the arena
+    uint32_t num_intersections; // I
     uint32_t num_visible;
     uint32_t pad0;
+    uint32_t row_cursor[16];  // tight projection: slots handed out of each of the arena's 16 shards
     unsigned long long num_processed[64]; // blend: staged list entries (64 partial sums)
     unsigned long long num_evaluated[64]; // blend: (wave, entry) pairs that survived the 8x8 cull
     uint32_t hist[4][256];    // instance sort: digit histograms -> exclusive digit bases
-    uint32_t ghist[2][256];   // gaussian sort
+    uint32_t rowhist[256];    // row sort: items per tile row (accumulated by the tight projection)
+};
+
+struct GsTightOut { // product-path outputs of the tight projection beside GaussianData and the count words (k_preprocess.hip)
+    uint32_t* arena; uint32_t* rowptr; GsControl* ctl;
 };
 
 struct GsScene {
     const float* px; const float* py; const float* pz; // f32[N] each: all the cull reads
     const float* smax; // f32[N]: largest log-scale of the gaussian (only read by tile-column slabs: conservative radius)
-    const float4* rec; // 256-byte record per gaussian, 16 x f32x4:
-                       //   [0] log-scale xyz, opacity logit   [1] rot r,x,y,z   [2..13] 48 SH floats (coefficient-major RGB)
-                       //   [14..15] padding (keeps every record on two 128-byte lines)
+    const float4* geo; // 32 bytes per gaussian: [0] log-scale xyz, opacity logit   [1] rot r,x,y,z
+    const float4* sh;  // 192 bytes per gaussian (three 64-byte sectors of its own): 48 SH floats, coefficient-major RGB
+                       // Two arrays, not one 256-byte record: the covariance phase reads 32 bytes, the colour phase -- long
+                       // after it, behind the tight row counting -- 192; in one record the first 128-byte line was fetched by
+                       // both (round 2: 1.19 GB of traffic for 0.78 GB of algorithmic bytes, profiles/README.md)
 };
 
 struct GsUniforms { // 160 B, renderer.ts:15-24

@@ -7,28 +7,20 @@ struct GsPreprocessLaunch { // the projection's launch as data (its uniforms are
     const void* func;
     uint32_t blocks;
     GsScene s; GsUniforms u; GsFrame f;
-    void* gdata; uint32_t* counts; uint32_t* keys; uint32_t* values; unsigned long long* status; uint32_t* ticket; GsControl* ctl;
-    void* args[10];
+    void* gdata; uint32_t* counts; GsTightOut to;
+    void* args[6];
 };
 void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
-                           bool tight);
+                           bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl);
 void gs_launch_preprocess(GsPreprocessLaunch& L, hipStream_t st);
-uint32_t gs_project_emit_blocks(uint32_t n);
-void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, uint32_t* keys,
-                            uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st);
 uint32_t gs_scan_blocks(uint32_t n);
-void gs_launch_scan(const uint32_t* counts, const uint32_t* gather, const uint32_t* n_dev, uint32_t n_static, uint32_t* offsets,
-                    uint32_t* vkey, uint32_t* vval, uint32_t* chunk_table, uint32_t chunk_cap, unsigned long long* status, uint32_t* ticket,
-                    GsControl* ctl, uint32_t write_totals, hipStream_t st, uint32_t* ccounts = nullptr, uint32_t* coffsets = nullptr);
+void gs_launch_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, unsigned long long* status, uint32_t* ticket, GsControl* ctl,
+                    hipStream_t st);
 uint64_t gs_emit_chunks(uint64_t capacity);
 // counts: tile-count words in the SAME order as offsets/perm (sorted order)
 void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
                              const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
                              uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st);
-// tight binning (gs_tight.h): counts / offsets / perm describe the visible gaussians in emission order (index or depth order)
-void gs_launch_emit_tight(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
-                          const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
-                          uint32_t hist_bits, uint32_t hist_passes, bool keys16, bool by_index, hipStream_t st);
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
@@ -48,8 +40,17 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
 void gs_launch_debug_view(const uint32_t* ranges, const GsFrame& f, uint32_t view, uint32_t* rgba8, hipStream_t st);
 void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t height, const uint32_t* d_px_bounds, uint32_t n_slabs,
                         uint64_t slab_stride_px, hipStream_t st);
-// k_gsort.hip: the visible gaussians sorted by depth bucket (stable) with their tile counts scanned in that order
+// k_gsort.hip: the visible gaussians sorted by depth bucket (stable) with their quantity (tile count / row-item slots) scanned in that order
 uint32_t gs_gsort_tiles(uint32_t n);
 uint64_t gs_gsort_scratch_bytes(uint32_t n);
-void gs_launch_gsort(const uint32_t* ids, const uint32_t* words, const GsControl* ctl, uint32_t n_max, void* scratch, uint32_t* perm,
-                     uint32_t* scounts, uint32_t* offsets, uint32_t* chunk_table, uint32_t chunk_cap, hipStream_t st);
+void gs_launch_gsort(const uint32_t* words, const uint32_t* aux_in, uint32_t n, void* scratch, uint32_t* perm, uint32_t* scounts, uint32_t* offsets,
+                     uint32_t* chunk_table, uint32_t chunk_cap, uint32_t* slot_src, uint32_t slot_cap, uint32_t* tot_visible,
+                     uint32_t* tot_quantity, hipStream_t st);
+// k_rows.hip: the tight row pipeline (row sort, per-chunk counts, scan, expansion into the final per-tile lists + ranges)
+uint32_t gs_rows_sort_tiles(uint64_t row_cap);
+uint32_t gs_rows_chunks(uint64_t row_cap);
+void gs_launch_rows(const uint32_t* arena, const uint32_t* slot_src, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
+                    uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
+                    uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg);
+void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,
+                                 uint32_t* keys, hipStream_t st);

@@ -88,10 +88,9 @@ struct gs_ctx {
     bool is_shadow = false;
     gs_ctx* last = nullptr;                   // who rendered the last frame (this or a shadow); nullptr = this
     uint32_t rr = 0;                          // next slot of the ring {this, shadows...}
-    uint64_t cap_hint = 0;                    // largest capacity any member has grown to
+    uint64_t cap_hint = 0, row_hint = 0;      // largest capacities any member of the ring has grown to
     bool tile_cull = true;                    // GS_OPT_TILE_CULL: tight (opacity-aware) binning in gs_render / gs_render_to
     bool last_tight = false;                  // the last frame used it
-    bool unfused = true;                      // GS_OPT_UNFUSED: separate projection / scan / emit kernels (default: measured faster)
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
     uint32_t blend_ablation = 0; // profiling only (GS_OPT_BLEND_ABLATION)
     uint32_t* blend_prof = nullptr; // profiling only (ablation bit 16): 4 words per blend walker
@@ -116,12 +115,16 @@ struct gs_ctx {
     GsControl* ctl = nullptr;
     unsigned long long* scan_status = nullptr;  // [2][scan blocks]
     uint32_t* tile_depth = nullptr;             // blend statistic: deepest staged entry per tile (quadrant kernel)
-    uint32_t* gsort_status = nullptr;           // gaussian-level sort by depth bucket
-    uint32_t* sort_status = nullptr;            // instance sort
-    uint32_t *vkeyA = nullptr, *vvalA = nullptr, *vkeyB = nullptr, *vvalB = nullptr; // (bucket, gaussian id) of visible gaussians
-    uint32_t* scounts = nullptr;                // tile-count words of the visible gaussians in depth-sorted order
-    void* gsort_scratch = nullptr;              // (bucket, tile) table of the gaussian-level counting sort (k_gsort.hip)
-    bool old_gsort = false;                     // GS_OPT_BLEND_ABLATION bit 18 (profiling): round 1's two look-back sweeps + second scan
+    uint32_t* sort_status = nullptr;            // instance sort (reference binning)
+    uint32_t* rows_status = nullptr;            // row sort (tight row pipeline)
+    uint32_t* perm = nullptr;                   // visible gaussians in (depth bucket, index) order (k_gsort.hip)
+    uint32_t* scounts = nullptr;                // their count words in that order
+    void* gsort_scratch = nullptr;              // (bucket, chunk) table of the gaussian-level counting sort
+    // tight row pipeline (k_rows.hip): row items in projection order / sorted by tile row, slot addresses in depth order
+    uint64_t row_cap = 0;
+    uint32_t *arena = nullptr, *rows_sorted = nullptr, *slot_src = nullptr, *rowptr = nullptr;
+    uint32_t *M3 = nullptr, *tileoff = nullptr, *rowtot = nullptr;
+    bool tight_ok = false;                      // the canvas has at most 255 tile rows and columns (8-bit digits of the row pipeline)
     bool scene_borrowed = false;                // gs_share_splats: scene_mem belongs to another context
     uint32_t last_passes = 0;
     bool last_by_index = true;
@@ -173,40 +176,50 @@ GS_EXPORT int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
 static void free_kv(gs_ctx* c) {
     hipFree(c->keysA); hipFree(c->valsA); hipFree(c->keysB); hipFree(c->valsB); hipFree(c->keysU); hipFree(c->valsU);
     hipFree(c->ctl_mem); hipFree(c->chunk_table); hipFree(c->keysG);
+    hipFree(c->arena); hipFree(c->rows_sorted); hipFree(c->slot_src); hipFree(c->M3);
     c->keysA = c->valsA = c->keysB = c->valsB = c->keysU = c->valsU = c->keysG = nullptr;
+    c->arena = c->rows_sorted = c->slot_src = c->M3 = nullptr;
     c->keysG_valid = false;
     c->chunk_table = nullptr;
     c->ctl_mem = nullptr;
 }
 
-// (key,value) arrays + the control/status block sized for `capacity` entries.
-static int32_t alloc_kv(gs_ctx* c, uint64_t capacity) {
+// (key,value) arrays for `capacity` instances, row-item arrays for `row_cap` slots, and the control/status block sized for both.
+static int32_t alloc_kv(gs_ctx* c, uint64_t capacity, uint64_t row_cap) {
     if (capacity >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "capacity %llu exceeds 2^30 intersections", (unsigned long long)capacity);
+    if (row_cap >= (1ull << 31)) return fail(GS_ERR_CAPACITY, "%llu row items exceed the 2^31 limit", (unsigned long long)row_cap);
     c->graph_valid = false; // (callers have drained the stream: no replay of the captured frame is in flight)
     free_kv(c);
     capacity = std::max<uint64_t>(capacity, 4096);
+    row_cap = (std::max<uint64_t>(row_cap, 4096) + 15) & ~(uint64_t)15;
     const size_t kb = (size_t)capacity * 4;
     HIP_TRY(hipMalloc((void**)&c->keysA, kb));
     HIP_TRY(hipMalloc((void**)&c->valsA, kb));
     HIP_TRY(hipMalloc((void**)&c->keysB, kb));
     HIP_TRY(hipMalloc((void**)&c->valsB, kb));
     HIP_TRY(hipMalloc((void**)&c->chunk_table, (size_t)gs_emit_chunks(capacity) * 4));
+    if (c->tight_ok) {
+        HIP_TRY(hipMalloc((void**)&c->arena, (size_t)row_cap * 12));
+        HIP_TRY(hipMalloc((void**)&c->rows_sorted, (size_t)row_cap * 12));
+        HIP_TRY(hipMalloc((void**)&c->slot_src, (size_t)row_cap * 4));
+        HIP_TRY(hipMalloc((void**)&c->M3, (size_t)gs_rows_chunks(row_cap) * 256 * 4));
+    }
     const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
-    // the fused projection+scan+emission kernel has 8x more (smaller) workgroups than the stand-alone scan
-    const size_t scan_one = (((size_t)gs_project_emit_blocks(c->n ? c->n : 1) + 1) * 8 + 255) & ~(size_t)255;
-    const size_t scan_sz = 2 * scan_one;
-    const size_t gsort_sz = (size_t)2 * gs_sort_tiles(c->n ? c->n : 1) * 256 * 4;
+    const size_t scan_sz = (((size_t)gs_scan_blocks(c->n ? c->n : 1) + 1) * 8 + 255) & ~(size_t)255;
     const size_t sort_sz = (size_t)std::max(c->passes, c->tile_passes) * gs_sort_tiles(capacity) * 256 * 4;
+    const size_t rows_sz = c->tight_ok ? (size_t)gs_rows_sort_tiles(row_cap) * 256 * 4 : 0;
     const size_t depth_sz = ((size_t)c->T * 4 + 255) & ~(size_t)255;
-    c->ctl_bytes = ctl_sz + depth_sz + scan_sz + gsort_sz + sort_sz;
+    c->ctl_bytes = ctl_sz + depth_sz + scan_sz + sort_sz + rows_sz;
     HIP_TRY(hipMalloc(&c->ctl_mem, c->ctl_bytes));
     c->ctl = (GsControl*)c->ctl_mem;
     c->tile_depth = (uint32_t*)((char*)c->ctl_mem + ctl_sz);
     c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz + depth_sz);
-    c->gsort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz);
-    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz + gsort_sz);
+    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz);
+    c->rows_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz + sort_sz);
     c->capacity = capacity;
+    c->row_cap = row_cap;
     c->frame.capacity = (uint32_t)capacity;
+    c->frame.row_cap = (uint32_t)row_cap;
     return GS_OK;
 }
 
@@ -247,6 +260,7 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     c->tile_bits = (tbits + c->tile_passes - 1) / c->tile_passes;
     c->tile16 = ((uint64_t)f.nty * f.ntx + f.ntx) < 0xFFFFull;
     if ((uint64_t)(f.ntx + 1) * (f.nty + 1) > GS_COUNT_MASK) { delete c; return fail(GS_ERR_INVALID_ARGUMENT, "gs_create: canvas has too many tiles"); }
+    c->tight_ok = f.ntx <= 255u && f.nty <= 255u; // the row pipeline's digits are a tile row / a tile column: 8 bits each (k_rows.hip)
 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
@@ -263,6 +277,8 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     HIP_TRY(hipHostMalloc((void**)&c->h_ctl, sizeof(GsControl), hipHostMallocDefault));
     memset(c->h_ctl, 0, sizeof(GsControl));
     HIP_TRY(hipMalloc((void**)&c->d_pxb, 65 * 4));
+    HIP_TRY(hipMalloc((void**)&c->tileoff, 256 * 256 * 4));
+    HIP_TRY(hipMalloc((void**)&c->rowtot, 256 * 4));
     HIP_TRY(hipMalloc((void**)&c->sticky, 4 * 4));
     HIP_TRY(hipMemset(c->sticky, 0, 4 * 4));
     HIP_TRY(hipHostMalloc((void**)&c->h_sticky, 4 * 4, hipHostMallocDefault));
@@ -289,8 +305,9 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     free_kv(c);
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts); hipFree(c->gsort_scratch);
+    hipFree(c->perm); hipFree(c->rowptr); hipFree(c->scounts); hipFree(c->gsort_scratch);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky); hipFree(c->blend_prof);
+    hipFree(c->tileoff); hipFree(c->rowtot);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_sticky) hipHostFree(c->h_sticky);
     if (c->have_events)
@@ -304,14 +321,14 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
 static int32_t wait_one(gs_ctx* c);
 GS_EXPORT int32_t gs_wait(gs_ctx* c);
 // Frees the previous scene and per-gaussian work arrays, allocates the work arrays for n gaussians.
-static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity = 0) {
+static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity = 0, uint64_t min_rows = 0) {
     c->graph_valid = false;
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->vkeyA); hipFree(c->vvalA); hipFree(c->vkeyB); hipFree(c->vvalB); hipFree(c->scounts); hipFree(c->gsort_scratch);
+    hipFree(c->perm); hipFree(c->rowptr); hipFree(c->scounts); hipFree(c->gsort_scratch);
     c->scounts = nullptr; c->gsort_scratch = nullptr;
     c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
-    c->vkeyA = c->vvalA = c->vkeyB = c->vvalB = nullptr;
+    c->perm = c->rowptr = nullptr;
     c->scene_borrowed = false;
     c->n = (uint32_t)n;
     c->frame.n = (uint32_t)n;
@@ -319,10 +336,8 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity =
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
     HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));
-    HIP_TRY(hipMalloc((void**)&c->vkeyA, std::max<size_t>(np * 4, 256)));
-    HIP_TRY(hipMalloc((void**)&c->vvalA, std::max<size_t>(np * 4, 256)));
-    HIP_TRY(hipMalloc((void**)&c->vkeyB, std::max<size_t>(np * 4, 256)));
-    HIP_TRY(hipMalloc((void**)&c->vvalB, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->perm, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc((void**)&c->rowptr, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->scounts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc(&c->gsort_scratch, gs_gsort_scratch_bytes((uint32_t)n)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
@@ -330,20 +345,24 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity =
     uint64_t cap = c->cfg.max_intersections ? c->cfg.max_intersections : std::max<uint64_t>(4 * n, 1u << 22);
     cap = std::max<uint64_t>(cap, min_capacity);
     cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
-    return alloc_kv(c, cap);
+    // row-item slots: a visible gaussian takes one per tile row of its ellipse (about three of them at 1080p, about 40 % of the
+    // gaussians visible); grown like the (key,value) capacity when a frame needs more
+    const uint64_t rows = std::max<uint64_t>(std::max<uint64_t>(2 * n, 1u << 20), min_rows);
+    return alloc_kv(c, cap, rows);
 }
 
 static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
     int32_t rc = alloc_per_gaussian(c, n);
     if (rc != GS_OK) return rc;
-    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and the records 256-byte aligned
-    const size_t bytes = np * 4 * 4 + (size_t)n * 256;
+    const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and both record arrays 256-byte aligned
+    const size_t bytes = np * 4 * 4 + np * 32 + (size_t)n * 192;
     HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
     char* p = (char*)c->scene_mem;
     GsScene& s = c->scene;
     s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
     s.smax = (float*)p; p += np * 4;
-    s.rec = (float4*)p;
+    s.geo = (float4*)p; p += np * 32;
+    s.sh = (float4*)p;
     if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -358,6 +377,7 @@ static int32_t drop_shadows(gs_ctx* c) {
     c->last = c;
     c->rr = 0;
     c->cap_hint = 0;
+    c->row_hint = 0;
     return GS_OK;
 }
 GS_EXPORT int32_t gs_share_splats(gs_ctx* c, gs_ctx* owner) {
@@ -369,7 +389,7 @@ GS_EXPORT int32_t gs_share_splats(gs_ctx* c, gs_ctx* owner) {
     if (c->pending) { int32_t rc = wait_one(c); if (rc != GS_OK) return rc; }
     // start from the capacity the owner has already grown to: a borrower exists to keep several frames in flight, and a
     // frame that overflows while others are queued behind it cannot be re-rendered (GS_ERR_TRUNCATED)
-    int32_t rc = alloc_per_gaussian(c, owner->n, c->cfg.max_intersections ? 0 : owner->capacity);
+    int32_t rc = alloc_per_gaussian(c, owner->n, c->cfg.max_intersections ? 0 : owner->capacity, owner->row_cap);
     if (rc != GS_OK) return rc;
     c->scene_mem = owner->scene_mem; // read-only during a frame; the owner must outlive this context
     c->scene = owner->scene;
@@ -413,76 +433,49 @@ static inline void mark(gs_ctx* c, int i) { // stage boundary i: closes stage i-
     }
 }
 
+static void mark_cb(void* p, int i) { mark((gs_ctx*)p, i); }
+
 // Every launch of one frame, in order, on the context's stream (directly, or into a stream capture).
-static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8, bool tight, bool fused) {
+static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8, bool tight) {
     const GsFrame& f = c->frame;
-    // tight emission: 4 workgroups per CU, all resident at once (5 fit), static chunk split.  Config B: 768 workgroups 206 us,
-    // 1024: 171, 1280: 219 (18 056 chunks on 5 120 waves = 3.5 rounds of chunks), 1536: 193, 2048: 180; drawing the chunks from
-    // 64 ticket words instead: 195-200.
-    const uint32_t emit_grid = c->grid_persist;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
-    if (fused) {
-        // experimental (GS_OPT_UNFUSED 0): projection, scan and emission in ONE launch; measured 9 % slower than the three
-        // launches at config B (the emission inherits the projection's 4 waves/SIMD and its workgroup granularity)
-        gs_launch_project_emit(c->scene, u, f, c->gdata, c->counts, c->keysA, c->valsA, c->scan_status, &c->ctl->pe_ticket, c->ctl, st);
-        mark(c, 1);
+    gs_preprocess_prepare(c->pre, c->scene, u, f, c->gdata, c->counts, tight, c->arena, c->rowptr, c->ctl);
+    gs_launch_preprocess(c->pre, st);
+    mark(c, 1);
+    const bool by_index = !tight && (debug || c->index_order);
+    bool keys16 = false;
+    if (tight) {
+        // The tight row pipeline (k_rows.hip).  Stage brackets: "scan" = the gaussian-level sort by depth bucket, "emit" = the
+        // row sort (the row items take write_tile_ids' place), "sort" = count + scan + expansion into the final lists,
+        // "ranges" = nothing (they fall out of the scan).
+        gs_launch_gsort(c->counts, c->rowptr, c->n, c->gsort_scratch, c->perm, c->scounts, c->offsets, nullptr, 0u, c->slot_src, (uint32_t)c->row_cap,
+                        &c->ctl->num_visible, &c->ctl->num_slots, st);
         mark(c, 2);
-    } else {
-        gs_preprocess_prepare(c->pre, c->scene, u, f, c->gdata, c->counts, tight);
-        gs_launch_preprocess(c->pre, st);
-        mark(c, 1);
-    }
-    const uint32_t scan_blocks = (uint32_t)(((size_t)gs_project_emit_blocks(c->n ? c->n : 1) + 1 + 31) & ~(size_t)31);
-    const bool by_index = debug || c->index_order;
-    if (fused) {
+        gs_launch_rows(c->arena, c->slot_src, c->rows_sorted, c->ctl, c->rows_status, (uint32_t)c->row_cap, c->M3, c->tileoff, c->rowtot, f, c->valsA,
+                       c->ranges, c->grid_persist / 4u, c->sticky, st, mark_cb, c);
+        c->keysS = nullptr;
+        c->valsS = c->valsA;
+        mark(c, 4);
     } else if (by_index) {
         // the reference's order: scan counts in gaussian order, emit in gaussian order, sort by the full key
-        if (tight) // the scan also compacts the visible gaussians (ids, counts, offsets): the emission walks only those
-            gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, c->chunk_table, (uint32_t)gs_emit_chunks(c->capacity),
-                           c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st, c->scounts, c->offsets);
-        else
-            gs_launch_scan(c->counts, nullptr, nullptr, c->n, c->offsets, nullptr, nullptr, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
+        gs_launch_scan(c->counts, c->n, c->offsets, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, st);
         mark(c, 2);
-        if (tight)
-            gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, c->vvalA, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2, 8u, 0u,
-                                 false, /*by_index=*/true, st);
-        else
-            gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);
+        gs_launch_emit(c->gdata, c->counts, c->offsets, nullptr, nullptr, f, c->keysA, c->valsA, c->ctl, st);
     } else {
         // Depth-ordered emission: the key is tile*1000 + bucket, and the required order inside a tile is (bucket,
         // gaussian index).  Sorting the N_vis visible GAUSSIANS by bucket first (stable, 10 bits, ~16x fewer elements
-        // than instances) and emitting their instances in that order leaves only the tile id for the stable instance
-        // sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
-        uint32_t *gk = nullptr, *gperm = nullptr;
-        if (!c->old_gsort) {
-            // the scan compacts the visible gaussians (ids + count words); ONE stable 10-bit counting sort then gives them in
-            // (bucket, index) order together with the prefix of their tile counts and the emission's chunk table (k_gsort.hip)
-            gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st,
-                           c->vkeyB, nullptr);
-            gs_launch_gsort(c->vvalA, c->vkeyB, c->ctl, c->n, c->gsort_scratch, c->vvalB, c->scounts, c->offsets, c->chunk_table,
-                            (uint32_t)gs_emit_chunks(c->capacity), st);
-            gperm = c->vvalB;
-        } else {
-            gs_launch_scan(c->counts, nullptr, nullptr, c->n, nullptr, c->vkeyA, c->vvalA, nullptr, 0u, c->scan_status, &c->ctl->scan_ticket[0], c->ctl, 1u, st);
-            // the last gaussian-level sweep also gathers the tile-count words into sorted order (c->scounts), so the second
-            // scan and the emission read them coalesced
-            gs_launch_sort(c->vkeyA, c->vvalA, c->vkeyB, c->vvalB, c->ctl, c->ctl->gsort_ticket, &c->ctl->ghist[0][0], &c->ctl->num_visible,
-                           c->n, 2, 5, 0, c->gsort_status, c->grid_persist, /*have_hist=*/true, c->counts, c->scounts, st, &gk, &gperm);
-            gs_launch_scan(c->scounts, nullptr, &c->ctl->num_visible, c->n, c->offsets, nullptr, nullptr, c->chunk_table,
-                           (uint32_t)gs_emit_chunks(c->capacity), c->scan_status + scan_blocks, &c->ctl->scan_ticket[1], c->ctl, 0u, st);
-        }
+        // than instances: k_gsort.hip) and emitting their instances in that order leaves only the tile id for the stable
+        // instance sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
+        gs_launch_gsort(c->counts, nullptr, c->n, c->gsort_scratch, c->perm, c->scounts, c->offsets, c->chunk_table,
+                        (uint32_t)gs_emit_chunks(c->capacity), nullptr, 0u, &c->ctl->num_visible, &c->ctl->num_intersections, st);
         mark(c, 2);
-        if (tight)
-            gs_launch_emit_tight(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, emit_grid,
-                                 c->tile_bits, c->tile_passes, c->tile16, /*by_index=*/false, st);
-        else
-            gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, gperm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
-                                    c->tile_bits, c->tile_passes, c->tile16, st);
+        gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, c->perm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
+                                c->tile_bits, c->tile_passes, c->tile16, st);
+        keys16 = c->tile16;
     }
-    const bool keys16 = !by_index && c->tile16;
     if (debug) {
         if (!c->keysU) {
             HIP_TRY(hipMalloc((void**)&c->keysU, (size_t)c->capacity * 4));
@@ -491,21 +484,23 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
         HIP_TRY(hipMemcpyAsync(c->keysU, c->keysA, (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(c->valsU, c->valsA, (size_t)c->capacity * 4, hipMemcpyDeviceToDevice, st));
     }
-    mark(c, 3);
-    if (by_index)
-        gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
-    else
-        gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
-                       (uint32_t)c->capacity, c->tile_passes, c->tile_bits, keys16 ? 0 : 1, c->sort_status, c->grid_persist, /*have_hist=*/true,
-                       nullptr, nullptr, st, &c->keysS, &c->valsS, keys16);
-    c->last_passes = by_index ? c->passes : c->tile_passes;
+    if (!tight) {
+        mark(c, 3);
+        if (by_index)
+            gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
+                           (uint32_t)c->capacity, c->passes, 8, 0, c->sort_status, c->grid_persist, false, nullptr, nullptr, st, &c->keysS, &c->valsS);
+        else
+            gs_launch_sort(c->keysA, c->valsA, c->keysB, c->valsB, c->ctl, c->ctl->sort_ticket, &c->ctl->hist[0][0], &c->ctl->num_intersections,
+                           (uint32_t)c->capacity, c->tile_passes, c->tile_bits, keys16 ? 0 : 1, c->sort_status, c->grid_persist, /*have_hist=*/true,
+                           nullptr, nullptr, st, &c->keysS, &c->valsS, keys16);
+        mark(c, 4);
+        if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st);
+        else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st); // streaming: 8 workgroups/CU
+    }
+    c->last_passes = tight ? 1u : (by_index ? c->passes : c->tile_passes);
     c->last_by_index = by_index;
     c->last_keys16 = keys16;
     c->last_tight = tight;
-    mark(c, 4);
-    if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st);
-    else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st); // streaming: 8 workgroups/CU
     mark(c, 5);
     uint32_t* target = ext_rgba8 ? (uint32_t*)ext_rgba8 : c->rgba8;
     if ((c->blend_ablation & 0x10000u) && !c->blend_prof) HIP_TRY(hipMalloc((void**)&c->blend_prof, (size_t)(1u << 20) * 16));
@@ -540,19 +535,18 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         c->index_order = (c->emit_order == 1);
     }
     // tight (opacity-aware) binning: product frames only; the sub-block mask shares the value word with the gaussian id
-    const bool tight = !debug && c->tile_cull && c->unfused && c->n < (1u << GS_ID_BITS);
-    const bool fused = !debug && c->index_order && !c->unfused;
+    const bool tight = !debug && c->tile_cull && c->tight_ok && c->n < (1u << GS_ID_BITS);
     // GS_OPT_FRAME_GRAPH: replay the captured frame instead of issuing its ~16 commands one by one (frames without per-stage
     // events or profiler output only).  The capture holds every buffer address and launch geometry of the frame, so anything
     // that moves a buffer or changes an option drops it (graph_valid); the emission order and the output address are part
     // of its identity.
-    const bool graphable = c->use_graph && !debug && !c->have_events && !fused && !(c->blend_ablation & 0x10000u) && c->n;
+    const bool graphable = c->use_graph && !debug && !c->have_events && !(c->blend_ablation & 0x10000u) && c->n;
     if (graphable) {
         if (!c->gexec || !c->graph_valid || c->gkey_index != c->index_order || c->gkey_tight != tight || c->gkey_ext != ext_rgba8) {
             if (c->gexec) HIP_TRY(hipStreamSynchronize(st)); // a replay of the old capture may still be running: not destroyed under it
             drop_graph(c);
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-            const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight, fused);
+            const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(st, &g);
             if (rc != GS_OK) { if (g) hipGraphDestroy(g); return rc; }
@@ -587,7 +581,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         HIP_TRY(hipGraphLaunch(c->gexec, st));
         c->graph_frames++;
     } else {
-        const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight, fused);
+        const int32_t rc = record_frame(c, u, debug, ext_rgba8, tight);
         if (rc != GS_OK) return rc;
     }
     c->keysG_valid = false;
@@ -621,22 +615,31 @@ static int32_t wait_one(gs_ctx* c) {
         if (!c->have_frame) return GS_OK;
         // the sticky words cover EVERY frame enqueued since the last gs_wait (the control block only the last one)
         const uint32_t over_frames = c->h_sticky[0], fault_any = c->h_sticky[1];
-        const uint64_t max_I = c->h_sticky[2];
-        if (over_frames || fault_any || max_I) HIP_TRY(hipMemset(c->sticky, 0, 4 * 4)); // stream is idle
-        c->h_sticky[0] = c->h_sticky[1] = c->h_sticky[2] = 0;
+        const uint64_t max_I = c->h_sticky[2], max_rows = c->h_sticky[3];
+        if (over_frames || fault_any || max_I || max_rows) HIP_TRY(hipMemset(c->sticky, 0, 4 * 4)); // stream is idle
+        c->h_sticky[0] = c->h_sticky[1] = c->h_sticky[2] = c->h_sticky[3] = 0;
         if (max_I > c->max_I_seen) c->max_I_seen = max_I;
         if (fault_any || c->h_ctl->fault) return fail(GS_ERR_DEVICE_FAULT, "a look-back spin exceeded its bound (fault word set)");
         const uint64_t I = c->h_ctl->num_intersections;
+        uint64_t rows_last = 0; // arena slots the last frame asked for: 16 shards as large as its fullest one
+        if (c->last_tight)
+            for (int k = 0; k < 16; ++k) rows_last = std::max<uint64_t>(rows_last, (uint64_t)c->h_ctl->row_cursor[k] * 16);
         const bool last_over = I > c->capacity || c->h_ctl->overflow;
         if (attempt == 0 && over_frames > (last_over ? 1u : 0u)) dropped = over_frames - (last_over ? 1u : 0u);
-        const uint64_t need = std::max<uint64_t>(I, max_I);
-        if (!last_over && need <= c->capacity) break;
-        // a frame overflowed the (key,value) capacity: grow geometrically; re-render the last frame if it was one of them
+        const uint64_t need = std::max<uint64_t>(I, max_I), need_rows = std::max<uint64_t>(rows_last, max_rows);
+        if (!last_over && need <= c->capacity && need_rows <= c->row_cap) break;
+        // a frame overflowed the (key,value) capacity or the row-item arena: grow geometrically; re-render the last frame if it was one of them
         if (need >= (1ull << 30)) return fail(GS_ERR_CAPACITY, "%llu intersections exceed the 2^30 limit", (unsigned long long)need);
-        uint64_t want = std::max<uint64_t>(need + need / 4, c->capacity * 2);
-        want = std::min<uint64_t>(want, (1ull << 30) - 1);
+        uint64_t want = c->capacity, want_rows = c->row_cap;
+        if (need > c->capacity) want = std::min<uint64_t>(std::max<uint64_t>(need + need / 4, c->capacity * 2), (1ull << 30) - 1);
+        if (need_rows > c->row_cap) want_rows = std::max<uint64_t>(need_rows + need_rows / 4, c->row_cap * 2);
+        if (want == c->capacity && want_rows == c->row_cap) { // flagged, yet nothing asks for more: the next attempt would be the same
+            if (last_over) return fail(GS_ERR_CAPACITY, "the frame reports an overflow that growing cannot fix (capacity %llu, rows %llu)",
+                                       (unsigned long long)c->capacity, (unsigned long long)c->row_cap);
+            break;
+        }
         hipFree(c->keysU); hipFree(c->valsU); c->keysU = c->valsU = nullptr;
-        int32_t rc = alloc_kv(c, want);
+        int32_t rc = alloc_kv(c, want, want_rows);
         if (rc != GS_OK) return rc;
         if (!last_over) break;
         if (attempt == 7) return fail(GS_ERR_CAPACITY, "capacity did not converge");
@@ -665,7 +668,8 @@ GS_EXPORT int32_t gs_wait(gs_ctx* c) {
         if (rc != GS_OK && first == GS_OK) { first = rc; memcpy(msg, g_err, sizeof(msg)); }
     }
     c->cap_hint = std::max(c->cap_hint, c->capacity);
-    for (gs_ctx* s : c->shadows) c->cap_hint = std::max(c->cap_hint, s->capacity);
+    c->row_hint = std::max(c->row_hint, c->row_cap);
+    for (gs_ctx* s : c->shadows) { c->cap_hint = std::max(c->cap_hint, s->capacity); c->row_hint = std::max(c->row_hint, s->row_cap); }
     if (first != GS_OK) memcpy(g_err, msg, sizeof(msg));
     return first;
 }
@@ -683,8 +687,8 @@ static int32_t add_shadow(gs_ctx* c) {
     s->is_shadow = true;
     rc = gs_share_splats(s, c);
     if (rc != GS_OK) { gs_destroy(s); return rc; }
-    s->emit_order = c->emit_order; s->tile_cull = c->tile_cull; s->unfused = c->unfused; s->debug_view = c->debug_view;
-    s->blend_ablation = c->blend_ablation; s->old_gsort = c->old_gsort; s->grid_persist = c->grid_persist; s->timed_from = 0;
+    s->emit_order = c->emit_order; s->tile_cull = c->tile_cull; s->debug_view = c->debug_view;
+    s->blend_ablation = c->blend_ablation; s->grid_persist = c->grid_persist; s->timed_from = 0;
     s->use_graph = c->use_graph;
     c->shadows.push_back(s);
     return GS_OK;
@@ -704,11 +708,11 @@ GS_EXPORT int32_t gs_render(gs_ctx* c, const void* uniforms) {
             const uint32_t slot = c->rr++ % (uint32_t)(c->shadows.size() + 1);
             t = slot ? c->shadows[slot - 1] : c;
         }
-        if (t->capacity < c->cap_hint) { // another member has met a bigger frame: grow before, not after, truncating one
+        if (t->capacity < c->cap_hint || t->row_cap < c->row_hint) { // another member has met a bigger frame: grow before, not after, truncating one
             HIP_TRY(hipSetDevice(t->cfg.device));
             if (t->pending) { int32_t rc = wait_one(t); if (rc != GS_OK && rc != GS_ERR_TRUNCATED) return rc; }
             hipFree(t->keysU); hipFree(t->valsU); t->keysU = t->valsU = nullptr;
-            int32_t rc = alloc_kv(t, c->cap_hint);
+            int32_t rc = alloc_kv(t, std::max(t->capacity, c->cap_hint), std::max(t->row_cap, c->row_hint));
             if (rc != GS_OK) return rc;
             t->have_frame = false;
         }
@@ -751,11 +755,12 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
         *ptr = which == GS_BUF_KEYS_UNSORTED ? c->keysU : c->valsU; *bytes = I * 4; return GS_OK;
     case GS_BUF_KEYS:
         *bytes = I * 4;
-        if (!c->last_keys16) { *ptr = c->keysS; return GS_OK; }
-        if (!c->keysG_valid) { // the frame was sorted on 16-bit tile ids: rebuild tile*1000 + bucket once
+        if (!c->last_keys16 && !c->last_tight) { *ptr = c->keysS; return GS_OK; }
+        if (!c->keysG_valid) { // the frame never held full keys (16-bit tile ids, or no keys at all on the tight row pipeline): rebuild tile*1000 + bucket once
             if (c->pending) { int32_t rc = wait_one(c); if (rc != GS_OK) return rc; }
             if (!c->keysG) HIP_TRY(hipMalloc((void**)&c->keysG, (size_t)c->capacity * 4));
-            gs_launch_rebuild_keys((const uint16_t*)c->keysS, c->valsS, c->counts, (uint32_t)I, c->n, c->last_tight ? GS_ID_MASK : 0xFFFFFFFFu, c->keysG, c->stream);
+            if (c->last_tight) gs_launch_rows_rebuild_keys(c->ranges, c->T, c->valsS, c->counts, (uint32_t)I, c->n, c->keysG, c->stream);
+            else gs_launch_rebuild_keys((const uint16_t*)c->keysS, c->valsS, c->counts, (uint32_t)I, c->n, 0xFFFFFFFFu, c->keysG, c->stream);
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->keysG_valid = true;
         }
@@ -791,6 +796,20 @@ GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t s
         const uint32_t nb = (c->frame.tile_size / 8) * (c->frame.tile_size / 8);
         const uint32_t all = nb >= 32 ? 0xFFFFFFFFu : (1u << nb) - 1u;
         for (uint64_t i = 0; i < bytes / 4; ++i) ((uint32_t*)dst)[i] = all;
+        return GS_OK;
+    }
+    if (which == GS_BUF_TILE_COUNTS && c->last_tight) {
+        // a tight frame's count words hold row-item slots (k_preprocess.hip): the tile counts of the tap are those of its lists
+        bytes = (uint64_t)c->n * 4;
+        if (written) *written = bytes;
+        if (!dst) return GS_OK;
+        if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
+        const uint64_t I = std::min<uint64_t>(c->h_ctl->num_intersections, c->capacity);
+        std::vector<uint32_t> v(I);
+        if (I) HIP_TRY(hipMemcpy(v.data(), c->valsS, I * 4, hipMemcpyDeviceToHost));
+        uint32_t* w = (uint32_t*)dst;
+        memset(w, 0, bytes);
+        for (uint64_t i = 0; i < I; ++i) { const uint32_t g = v[i] & GS_ID_MASK; if (g < c->n) w[g]++; }
         return GS_OK;
     }
     int32_t rc = tap(c, which, &p, &bytes);
@@ -861,6 +880,11 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* root, gs_stats* out) {
         out->graph_frames = root->graph_frames;
         for (gs_ctx* s : root->shadows) out->graph_frames += s->graph_frames;
         out->tight_binning = c->last_tight ? 1u : 0u;
+        out->row_capacity = c->row_cap;
+        if (c->last_tight) {
+            out->num_row_items = c->h_ctl->num_items;
+            out->num_row_slots = c->h_ctl->num_slots;
+        }
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
         if (c->blend_walkers >= 4) { // 8x8-block walkers (4 per 16-tile, 16 per 32-tile): sum over tiles of the deepest walker
             std::vector<uint32_t> depth(c->T);
@@ -928,11 +952,11 @@ static int32_t set_option_one(gs_ctx* c, int32_t key, int64_t value) {
     c->graph_valid = false; // a captured frame holds the options it was recorded with
     switch (key) {
     case GS_OPT_FRAME_GRAPH: c->use_graph = (value != 0); return GS_OK;
-    case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value & 0x3FFFFu; c->old_gsort = ((uint32_t)value & 0x40000u) != 0; return GS_OK;
+    case GS_OPT_BLEND_ABLATION: c->blend_ablation = (uint32_t)value & 0x3FFFFu; return GS_OK;
     case GS_OPT_PERSISTENT_GRID: if (value <= 0) break; c->grid_persist = (uint32_t)value; return GS_OK;
     case GS_OPT_RESET_TIMING: c->timed_from = c->frames; c->max_I_seen = 0; c->truncated_frames = 0; return GS_OK;
     case GS_OPT_EMIT_ORDER: if (value < 0 || value > 2) break; c->emit_order = (int)value; return GS_OK;
-    case GS_OPT_UNFUSED: c->unfused = (value != 0); return GS_OK;
+    case GS_OPT_UNFUSED: return GS_OK; // (removed in ABI 3: the fused projection+scan+emission launch measured slower; accepted, ignored)
     case GS_OPT_DEBUG_VIEW: if (value < 0 || value > 4) break; c->debug_view = (uint32_t)value; return GS_OK;
     case GS_OPT_TILE_CULL: c->tile_cull = (value != 0); return GS_OK;
     default: break;
@@ -1168,8 +1192,7 @@ GS_EXPORT int32_t gs_exclusive_scan_u32(int32_t device, uint32_t* data, uint64_t
     TRY2(hipMemset(ctl_mem, 0, ctl_sz + st_sz));
     TRY2(hipMemcpy(in, data, kb, hipMemcpyHostToDevice));
     GsControl* ctl = (GsControl*)ctl_mem;
-    gs_launch_scan(in, nullptr, nullptr, (uint32_t)n, out, nullptr, nullptr, nullptr, 0u, (unsigned long long*)((char*)ctl_mem + ctl_sz),
-                   &ctl->scan_ticket[0], ctl, 1u, nullptr);
+    gs_launch_scan(in, (uint32_t)n, out, (unsigned long long*)((char*)ctl_mem + ctl_sz), &ctl->scan_ticket[0], ctl, nullptr);
     TRY2(hipGetLastError());
     TRY2(hipDeviceSynchronize());
     GsControl h;

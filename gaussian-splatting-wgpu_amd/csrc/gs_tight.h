@@ -77,7 +77,7 @@ __device__ __forceinline__ bool tight_chord(const TightG& g, float dy, float& xl
     const float p1 = t * t, p2 = g.cxz * (dy * dy), p3 = g.lim2 * g.cx;
     const float up = ((p1 - p2) + p3) + 1.0e-5f * ((p1 + p2) + p3);
     if (!(up >= 0.0f)) return false;
-    const float hw = __builtin_sqrtf(up) * g.rcx;
+    const float hw = __builtin_amdgcn_sqrtf(up) * g.rcx; // v_sqrt_f32 (1 ulp): `up` is inflated by 1e-5 of its terms, the strip adds 0.02 px of slack
     const float c = -(t * g.rcx);
     xlo = c - hw;
     xhi = c + hw;
@@ -203,4 +203,71 @@ __device__ __forceinline__ void tight_substrips(const TightG& g, uint32_t ty, ui
     const TightChord cm = tight_chord_at(g, ym);
     if (tight_strip(g, ym, yb, cm.v, cm.lo, cm.hi, cb.v, cb.lo, cb.hi, plo, phi)) tight_cols(plo, phi, (float)sub, inv_sub, cmin, cmax, lo[0], hi[0]);
     if (tight_strip(g, ya, ym, ca.v, ca.lo, ca.hi, cm.v, cm.lo, cm.hi, plo, phi)) tight_cols(plo, phi, (float)sub, inv_sub, cmin, cmax, lo[1], hi[1]);
+}
+
+// ---- row items (the unit of the tight row pipeline, k_rows.hip) ----------------------------------------------------------
+// A gaussian's instances are, per tile row of its rect, ONE run of tiles (E ∩ strip is convex) plus at most one aliased
+// instance.  The projection computes each run once, with the sub-block intervals of its two half strips, and stores it as a
+// 12-byte ROW ITEM; everything downstream (sorting the items by tile row, expanding them into per-tile lists) is integer work
+// on these records -- round 2's emission recomputed the chords of every row from the 64-byte GaussianData record
+// (295 lane-instructions per instance, instruction bound at 0.147 of the HBM roofline).
+//   w0  gaussian id (28 bits); 0xFFFFFFFF = hole (a slot whose row turned out empty)
+//   w1  tile row | first tile column << 8 | (tiles - 1) << 16                     (each < 256: tight binning needs ntx, nty <= 255)
+//   w2  l0 | h0 << 8 | l1 << 16 | h1 << 24: sub-block columns [l, h) touched in the upper / lower half strip, relative to the
+//       run's first sub-block column (sub-block = tile_size / 2, or the whole 8-pixel tile: then only l0, h0); h = 255 = no end
+// Slots of a gaussian whose rows are [ra, rb): slot s < rb - ra is the run of row ra + s; with an aliased column (SURVEY A.3:
+// column ntx of row ty IS tile (ty + 1, 0)) slot (rb - ra) + s is the aliased instance of row ra + s, an item of its own in
+// tile row ty + 1, column 0, one tile long.
+#define GS_ROW_HOLE 0xFFFFFFFFu
+#define GS_ROW_MAX_DIM 255u
+__device__ __forceinline__ uint32_t tight_enc8(int v) { return v <= 0 ? 0u : (v >= 255 ? 255u : (uint32_t)v); }
+__device__ __forceinline__ uint32_t tight_pack_intervals(const int lo[2], const int hi[2], int cmin, uint32_t ncols) {
+    if (ncols > 254u) return 0xFF00FF00u; // a run too long for 8-bit intervals: every sub-block flagged (conservative)
+    uint32_t w = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint32_t l = 0, h = 0;
+        if (lo[s] <= hi[s]) { l = tight_enc8(lo[s] - cmin); h = tight_enc8(hi[s] + 1 - cmin); }
+        w |= (l | (h << 8)) << (16 * s);
+    }
+    return w;
+}
+// Slot `slot` of a gaussian (see above).  Returns the number of tiles of the item (0: hole) and its words w1, w2.
+__device__ __forceinline__ uint32_t tight_slot_item(const TightG& g, uint32_t slot, uint32_t ra, uint32_t nrows, uint32_t ts, float inv_ts, uint32_t sub,
+                                                    float inv_sub, uint32_t ns, uint32_t nty, uint32_t xa, uint32_t wmain, uint32_t alias, uint32_t& w1,
+                                                    uint32_t& w2) {
+    w1 = 0u; w2 = 0u;
+    TightRow r;
+    int lo[2], hi[2];
+    if (slot < nrows) {
+        const uint32_t ty = ra + slot;
+        const TightChord cb = tight_chord_at(g, tight_row_dy(g, ty, ts)), ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, ts));
+        const uint32_t len = tight_row(g, ty, ts, inv_ts, nty, xa, wmain, 0u, cb, ca, r);
+        if (!len) return 0u;
+        const int cmin = r.tlo * (int)ns, cmax = (r.thi + 1) * (int)ns - 1;
+        tight_substrips(g, ty, ts, sub, inv_sub, cmin, cmax, cb, ca, lo, hi);
+        w1 = ty | ((uint32_t)r.tlo << 8) | ((len - 1u) << 16);
+        w2 = tight_pack_intervals(lo, hi, cmin, len * ns);
+        return len;
+    }
+    if (!alias) return 0u;
+    const uint32_t ty = ra + (slot - nrows);
+    const TightChord cb = tight_chord_at(g, tight_row_dy(g, ty, ts)), ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, ts));
+    if (!tight_row(g, ty, ts, inv_ts, nty, xa, 0u, 1u, cb, ca, r)) return 0u;
+    const TightChord c2 = tight_chord_at(g, tight_row_dy(g, ty + 2u, ts));
+    tight_substrips(g, ty + 1u, ts, sub, inv_sub, 0, (int)ns - 1, ca, c2, lo, hi);
+    w1 = (ty + 1u); // tile (ty + 1, 0), one tile
+    w2 = tight_pack_intervals(lo, hi, 0, ns);
+    return 1u;
+}
+// Sub-block mask of tile q (0-based inside the run) of an item: bit 0 / 1 = left / right sub-block of the upper half strip,
+// bits 2 / 3 of the lower one (ns = 2); bit 0 = the tile (ns = 1).
+__device__ __forceinline__ uint32_t tight_item_mask(uint32_t w2, uint32_t q, uint32_t ns) {
+    const uint32_t l0 = w2 & 0xFFu, h0 = (w2 >> 8) & 0xFFu, l1 = (w2 >> 16) & 0xFFu, h1 = w2 >> 24;
+    if (ns == 2u) {
+        const uint32_t c0 = 2u * q, c1 = c0 + 1u;
+        return (uint32_t)(l0 <= c0 && (c0 < h0 || h0 == 255u)) | ((uint32_t)(l0 <= c1 && (c1 < h0 || h0 == 255u)) << 1) |
+               ((uint32_t)(l1 <= c0 && (c0 < h1 || h1 == 255u)) << 2) | ((uint32_t)(l1 <= c1 && (c1 < h1 || h1 == 255u)) << 3);
+    }
+    return (uint32_t)(l0 <= q && (q < h0 || h0 == 255u));
 }

@@ -7,44 +7,42 @@
 // HBM layout (the reference keeps 320-byte AoS records, 84 B of which are padding, and reads the whole
 // record of every gaussian, culled or not).  The scene is re-laid-out once at upload into
 //   px,py,pz  f32[N] planes      12 B read by EVERY gaussian: the frustum cull needs nothing else
-//   rec       256 B per gaussian  {log-scale, opacity | rot | 48 SH floats | pad}, 256-byte aligned
-// and the kernel runs in three phases per workgroup of 512 gaussians:
+//   geo       32 B per gaussian   {log-scale, opacity | rot}
+//   sh        192 B per gaussian  48 SH floats (three 64-byte sectors of its own)
+// and the kernel runs in three phases per workgroup of 512 (4096 in the tight path) gaussians:
 //   1. cull on the position planes (coalesced 4-byte loads), survivors compacted through LDS;
-//   2. DENSE lanes (one survivor each) read the first 32 B of their record (scale, rot): covariance,
-//      conic, radius, rect, tile count -- and, for a tile-column slab, drop out if no instance lands in it;
-//   3. the rest of the record (opacity + 192 B of SH): colour, sigmoid, the 64-byte GaussianData store.
-// A culled gaussian costs 12 B, a visible one 12 + 224 B in full 64-byte sectors of its own record
-// (plane-per-attribute layouts drag in the neighbours' sectors: at 43 % visibility that doubled the
-// traffic), and the ~1000-instruction body runs on full waves instead of 43 %-populated ones.
+//   2. DENSE lanes (one survivor each) read their 32 B of geometry: covariance, conic, radius, rect, tile count
+//      -- and, for a tile-column slab, drop out if no instance lands in it; the tight path then computes the
+//      gaussian's ROW ITEMS (gs_tight.h) with the whole workgroup, one (survivor, tile row) per thread;
+//   3. the 192 B of SH: colour, sigmoid, the 64-byte GaussianData store.
+// A culled gaussian costs 12 B, a visible one 12 + 32 + 192 B (round 2 kept geometry and SH in one 256-byte record
+// whose first 128-byte line was fetched by phase 2 AND, long after, by phase 3: 1.53x the algorithmic traffic).
 // Algorithmic bytes per gaussian: 12 (culled) or 236 (visible) read; 4 (count) + 56 (visible) written.
 // Bound: HBM.  No MFMA (no contraction on this path).
 #include "gs_device.h"
 #include "gs_kernels.h"
 #include "gs_tight.h"
 
-// ---- upload: 320-byte AoS (ply.ts:190-198) -> position planes + 256-byte records ------------------
+// ---- upload: 320-byte AoS (ply.ts:190-198) -> position planes + geometry / SH records ---------------
 // One thread per (gaussian, 16-byte column of the source record); runs once per scene.
 __global__ __launch_bounds__(256) void gs_repack_kernel(const float4* __restrict__ aos, uint32_t n, float* px, float* py,
-                                                         float* pz, float* smax, float* rec) {
+                                                         float* pz, float* smax, float* geo, float* sh) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t total = (uint64_t)n * 20; // 20 float4 per source record
     if (t >= total) return;
     const uint32_t g = (uint32_t)(t / 20), c = (uint32_t)(t % 20);
     const float4 v = aos[t];
-    float* r = rec + (uint64_t)g * 64;
+    float* r = geo + (uint64_t)g * 8;
     if (c == 0) { px[g] = v.x; py[g] = v.y; pz[g] = v.z; }
     else if (c == 1) { r[0] = v.x; r[1] = v.y; r[2] = v.z; smax[g] = __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z)); }
     else if (c == 2) { r[4] = v.x; r[5] = v.y; r[6] = v.z; r[7] = v.w; }
     else if (c == 3) { r[3] = v.x; }
     else {
-        const uint32_t k = c - 4; // SH coefficient k: rgb -> packed floats 3k..3k+2 of 48, at record float 8+
-        r[8 + 3 * k + 0] = v.x;
-        r[8 + 3 * k + 1] = v.y;
-        r[8 + 3 * k + 2] = v.z;
-        if (k == 15) {
-#pragma unroll
-            for (int j = 56; j < 64; ++j) r[j] = 0.0f;
-        }
+        const uint32_t k = c - 4; // SH coefficient k: rgb -> packed floats 3k..3k+2 of the gaussian's 48
+        float* q = sh + (uint64_t)g * 48 + 3 * k;
+        q[0] = v.x;
+        q[1] = v.y;
+        q[2] = v.z;
     }
 }
 
@@ -90,7 +88,7 @@ __device__ __forceinline__ float sigmoid_ref(float o) {
 }
 
 // compute_color_from_sh (:240-280): the view direction's SH basis times the 16 RGB coefficients of the record, + 0.5, clamped.
-__device__ __forceinline__ void sh_colour(const float4* __restrict__ rec, float x, float y, float z, const GsUniforms& u, float col[3]) {
+__device__ __forceinline__ void sh_colour(const float4* __restrict__ sh, float x, float y, float z, const GsUniforms& u, float col[3]) {
     const float dx = x - u.cam[0], dy = y - u.cam[1], dz = z - u.cam[2];
     const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
     const float X = dx / dl, Y = dy / dl, Z = dz / dl;
@@ -114,7 +112,7 @@ __device__ __forceinline__ void sh_colour(const float4* __restrict__ rec, float 
 #ifdef PRE_ABLATE_SH
         const float4 vv = make_float4(X, Y, Z, 0.5f); // PROFILING BUILD ONLY: no SH reads
 #else
-        const float4 vv = rec[2 + p];
+        const float4 vv = sh[p];
 #endif
         shv[4 * p + 0] = vv.x; shv[4 * p + 1] = vv.y; shv[4 * p + 2] = vv.z; shv[4 * p + 3] = vv.w;
     }
@@ -157,60 +155,51 @@ __device__ __forceinline__ bool in_frustum_slab(const GsUniforms& u, const GsFra
     return (reach || alias) || !(rb == rb);
 }
 
-#define PRE_G 512 // gaussians per workgroup
+#define PRE_G 512 // gaussians per cull chunk
 #ifndef PRE_WAVES
 #define PRE_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
-#define PE_AGG (1ull << 62)
-#define PE_PREFIX (2ull << 62)
-#define PE_MASK (3ull << 62)
+typedef uint32_t gs_row_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
 
-// FUSED = false: projection only (tile counts + GaussianData); the scan and the key emission are separate kernels
-//                (gs_render_debug, which must expose the reference's intermediate buffers, and the experimental
-//                depth-ordered pipeline).
-// FUSED = true : projection, the exclusive scan of the tile counts AND the (key,value) emission in ONE pass: a workgroup
-//                scans its 512 counts in LDS, gets its base offset by decoupled look-back over one 8-byte
-//                {flag, visible, sum} granule per workgroup (ticket-ordered, so it only waits on workgroups that have
-//                started) and expands its instances with coalesced stores straight from the rects it still holds in
-//                LDS.  Emission order is the reference's (gaussian index, y, x); offsets/rects never travel through HBM.
-// TIGHT = true : the product path's opacity-aware binning (gs_tight.h): the tile count is the number of tiles of the rect that
-//                intersect the gaussian's alpha >= 1/255 ellipse (0 when its opacity is below 1/255), and the emission
-//                (gs_emit_tight_kernel) writes exactly those.  gs_render_debug and GS_OPT_TILE_CULL 0 use TIGHT = false.
-// NB           : 512-gaussian chunks per workgroup.  A tile-column slab keeps ~1/G of the frustum survivors, so with one
-//                chunk per workgroup the dense phases would run on a few dozen lanes each, one latency-bound workgroup after
-//                the other (131-145 us per rank at 8 slabs, the O(N) part that does not shrink with the slab).  With NB = 8
-//                a workgroup culls 4 096 gaussians (positions of 8 per thread in flight at a time), appends the survivors to
-//                ONE list in LDS and then runs the dense phases on full waves.
-template <bool FUSED, bool TIGHT = false, int NB = 1>
+// Product-path outputs of the tight projection (TIGHT = true), beside GaussianData and the count words:
+//   arena   : 12-byte row items (gs_tight.h), handed out to workgroups by 16 bump cursors (GsControl::row_cursor; shard =
+//             workgroup % 16 owns arena slots [shard * f.row_cap / 16, ...)): a gaussian's slots are consecutive, in row order
+//   rowptr  : first arena slot of every visible gaussian
+//   counts  : SLOTS of the gaussian (rows, twice that with an aliased column) | depth bucket << 22 -- what the gaussian-level
+//             sort (k_gsort.hip) scans; 0 when no tile survives (the tile-count tap of a tight frame is derived from the lists)
+//   GsControl::rowhist[r] += items of tile row r (the digit histogram of the row sort, k_rows.hip)
+
+// TIGHT = true : the product path's opacity-aware binning (gs_tight.h): an instance (gaussian, tile) exists only if the tile
+//                intersects the gaussian's alpha >= 1/255 ellipse; the kernel writes the gaussian's row items.
+//                gs_render_debug and GS_OPT_TILE_CULL 0 use TIGHT = false: the reference's rect count, nothing else.
+// NB           : 512-gaussian cull chunks per workgroup.  NB = 8 (tight path, and narrow slabs): a workgroup culls 4 096
+//                gaussians (positions of 8 per thread in flight at a time), appends the survivors to ONE list in LDS and runs
+//                the dense phases on full waves.  A tile-column slab keeps ~1/G of the frustum survivors: with one chunk per
+//                workgroup its dense phases would run on a few dozen lanes each (131-145 us per rank at 8 slabs).  The tight
+//                path always uses 8: 1 490 workgroups at 6.1 M gaussians keep the bump cursors and the row histogram cold
+//                (one atomic per workgroup and trip / per touched tile row instead of eight times as many).
+template <bool TIGHT, int NB>
 __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
-                                                             uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ values, unsigned long long* status,
-                                                             uint32_t* ticket, GsControl* ctl) {
+                                                             uint32_t* __restrict__ tile_counts, GsTightOut to) {
     __shared__ uint32_t s_ids[PRE_G * NB];
     __shared__ uint32_t s_cnt[2][4];
-    __shared__ uint32_t s_ecnt[FUSED ? PRE_G : 1]; // tile count, then exclusive prefix, of the v-th survivor
-    __shared__ uint32_t s_erow[FUSED ? PRE_G : 1]; // xa | wmain<<16 | alias<<31
-    __shared__ uint32_t s_eyb[FUSED ? PRE_G : 1];  // y0 | bucket<<16
     __shared__ uint32_t s_misc[8];
-    // TIGHT: the tight tile counts of up to 256 survivors at a time are computed by the whole workgroup, one (survivor, tile
-    // row) item per thread and trip (a lane looping over its own rect's rows would wait for the tallest rect of its wave)
+    // TIGHT: the row items of up to 256 survivors at a time are computed by the whole workgroup, one (survivor, slot) per
+    // thread and trip (a lane looping over its own rect's rows would wait for the tallest rect of its wave)
     __shared__ float4 s_tA[TIGHT ? 256 : 1], s_tB[TIGHT ? 256 : 1], s_tC[TIGHT ? 256 : 1]; // gx gy cx cy | cz cxz lim2 rcx | xmax dyR eR mode
-    __shared__ uint32_t s_trow[TIGHT ? 256 : 1], s_tcol[TIGHT ? 256 : 1], s_trp[TIGHT ? 256 : 1], s_tcnt[TIGHT ? 256 : 1];
+    __shared__ uint32_t s_trow[TIGHT ? 256 : 1], s_tcol[TIGHT ? 256 : 1], s_trp[TIGHT ? 256 : 1], s_tcnt[TIGHT ? 256 : 1], s_tgid[TIGHT ? 256 : 1];
     __shared__ uint32_t s_tw[4];
+    __shared__ uint32_t s_rowhist[TIGHT ? 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint32_t bid = blockIdx.x;
-    if (FUSED) { // dynamic workgroup id: a workgroup only ever waits on lower tickets, which are already running
-        if (tid == 0) s_misc[0] = atomicAdd(ticket, 1u);
-        __syncthreads();
-        bid = s_misc[0];
-    }
+    const uint32_t bid = blockIdx.x;
     const uint32_t base = bid * (PRE_G * NB);
+    if (TIGHT) s_rowhist[tid] = 0u;
 
     // ---- phase 1: in_frustum (:108-125) on the position planes, survivors compacted ----
     uint32_t nvis = 0;
     if (NB > 1) {
-        // (slabs only) survivors are appended wave by wave through one LDS counter: their order in the list is free, every
-        // output of the unfused kernel is indexed by the gaussian
+        // survivors are appended wave by wave through one LDS counter: their order in the list is free, every output is
+        // indexed by the gaussian
         if (tid == 0) s_misc[1] = 0u;
         __syncthreads();
 #pragma unroll 1
@@ -220,7 +209,8 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             for (int k = 0; k < 8; ++k) {
                 const uint32_t i = base + (uint32_t)(h * 8 + k) * 256u + tid;
                 const bool in = i < f.n;
-                X[k] = in ? s.px[i] : 0.0f; Y[k] = in ? s.py[i] : 0.0f; Z[k] = in ? s.pz[i] : 0.0f; S[k] = in ? s.smax[i] : 0.0f;
+                X[k] = in ? s.px[i] : 0.0f; Y[k] = in ? s.py[i] : 0.0f; Z[k] = in ? s.pz[i] : 0.0f;
+                S[k] = (in && !f.full) ? s.smax[i] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -270,17 +260,19 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             if (vis[k]) s_ids[before + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] = k * 256 + tid;
         }
         __syncthreads();
-
     }
 
     // ---- phases 2 and 3: one survivor per lane ----
     const uint32_t trips = (nvis + 255u) / 256u;
+    const uint32_t ts_ = f.tile_size, sub = ts_ >= 16u ? ts_ / 2u : ts_, ns = ts_ / sub;
+    const float inv_ts = 1.0f / (float)ts_, inv_sub = 1.0f / (float)sub;
+    const uint32_t shard = bid & 15u, shard_cap = f.row_cap >> 4;
     for (uint32_t v = tid, trip = 0; TIGHT ? trip < trips : v < nvis; v += 256, ++trip) {
         // TIGHT: every thread takes every trip (workgroup barriers inside); a thread without a survivor recomputes the
         // last one and writes nothing
         const bool active = v < nvis;
         const uint32_t i = base + s_ids[active ? v : nvis - 1u];
-        const float4* rec = s.rec + (uint64_t)i * 16;
+        const float4* geo = s.geo + (uint64_t)i * 2;
         const float x = s.px[i], y = s.py[i], z = s.pz[i];
         float ph[4], pv[4];
         m4_mulv(u.proj, x, y, z, ph);
@@ -289,8 +281,8 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         m4_mulv(u.view, x, y, z, pv);
         const float uvx = (ndx * 0.5f) + 0.5f, uvy = (ndy * 0.5f) + 0.5f; // :54
         // compute_cov3d (:127-162)
-        const float4 so = rec[0]; // log-scale xyz, opacity logit
-        const float4 q = rec[1];
+        const float4 so = geo[0]; // log-scale xyz, opacity logit
+        const float4 q = geo[1];
         const float mod = u.scale_modifier;
         const float sc[3] = {gs_exp(so.x) * mod, gs_exp(so.y) * mod, gs_exp(so.z) * mod};
         const float len = __builtin_sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
@@ -349,13 +341,12 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             uint32_t xa, wmain, alias; // columns of the rect inside this ctx's slab (the whole rect when f.full)
             slab_cols(rminx, rmaxx, f, xa, wmain, alias);
             count = f.full ? (rmaxy - rminy) * (rmaxx - rminx) /* :86 */ : (rmaxy - rminy) * (wmain + alias);
-            if (FUSED) s_erow[v] = xa | (wmain << 16) | (alias << 31);
             if (TIGHT) { t_xa = xa; t_wmain = wmain; t_alias = alias; }
         }
+        uint32_t nslots = 0, rowptr = 0;
         if (TIGHT) {
-            const float inv_ts = 1.0f / (float)f.tile_size;
-            if (trip) __syncthreads(); // the previous trip's row items are done with the LDS records
-            uint32_t nrows = 0, ra = 0;
+            if (trip) __syncthreads(); // the previous trip's slot items are done with the LDS records
+            uint32_t ra = 0;
             if (active && count) {
                 opacity = sigmoid_ref(so.w);
                 const TightG tg = tight_setup(uvx, uvy, conx, cony, conz, opacity, (float)f.width, (float)f.height);
@@ -363,29 +354,40 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
                 else {
                     uint32_t rb;
                     tight_rows(tg, rminy, rmaxy, f.tile_size, inv_ts, f.nty, t_alias, ra, rb);
-                    nrows = rb - ra;
-                    if (!nrows) count = 0u;
+                    nslots = (rb - ra) * (1u + t_alias);
+                    if (!nslots) count = 0u;
                     s_tA[tid] = make_float4(tg.gx, tg.gy, tg.cx, tg.cy);
                     s_tB[tid] = make_float4(tg.cz, tg.cxz, tg.lim2, tg.rcx);
                     s_tC[tid] = make_float4(tg.xmax, tg.dyR, tg.eR, __uint_as_float(tg.mode));
-                    s_trow[tid] = ra;
+                    s_trow[tid] = ra | ((rb - ra) << 16);
                     s_tcol[tid] = t_xa | (t_wmain << 16) | (t_alias << 31);
+                    s_tgid[tid] = i;
                 }
+            } else {
+                count = 0u;
             }
             s_tcnt[tid] = 0u;
-            const uint32_t rincl = wave_incl_scan(nrows, lane);
+            const uint32_t rincl = wave_incl_scan(nslots, lane);
             if (lane == 63) s_tw[w] = rincl;
             __syncthreads();
             uint32_t wbase = 0, R = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { if (k < (int)w) wbase += s_tw[k]; R += s_tw[k]; }
-            s_trp[tid] = wbase + rincl - nrows;
+            const uint32_t myrp = wbase + rincl - nslots;
+            s_trp[tid] = myrp;
+            if (tid == 0) { // this trip's slots: one bump of the shard's cursor
+                uint32_t at = 0, ok = 1u;
+                if (R) {
+                    at = atomicAdd(&to.ctl->row_cursor[shard], R);
+                    if (at > shard_cap || R > shard_cap - at) { ok = 0u; to.ctl->overflow = 1u; } // the frame does not fit: gs_wait grows the arena and re-renders
+                }
+                s_misc[2] = at; s_misc[3] = ok;
+            }
             __syncthreads();
-#ifdef PRE_ABLATE_ROWS
-            if (R > 0x7FFFFFFFu) // PROFILING BUILD ONLY: the per-row tight count is skipped
-#endif
+            const uint32_t abase = shard * shard_cap + s_misc[2];
+            const bool ok = s_misc[3] != 0u;
             for (uint32_t ri = tid; ri < R; ri += 256) {
-                uint32_t j = 0; // largest j with rp[j] <= ri (row-less survivors share their successor's prefix)
+                uint32_t j = 0; // largest j with rp[j] <= ri (slot-less survivors share their successor's prefix)
 #pragma unroll
                 for (int step = 128; step >= 1; step >>= 1) {
                     const uint32_t m = j + step;
@@ -395,29 +397,34 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
                 TightG g;
                 g.gx = a.x; g.gy = a.y; g.cx = a.z; g.cy = a.w; g.cz = b.x; g.cxz = b.y; g.lim2 = b.z; g.rcx = b.w;
                 g.xmax = c4.x; g.dyR = c4.y; g.eR = c4.z; g.mode = __float_as_uint(c4.w); g.ymax = 0.0f;
-                const uint32_t cw = s_tcol[j];
-                const uint32_t ty = s_trow[j] + (ri - s_trp[j]);
-                TightRow r;
-                const TightChord cb = tight_chord_at(g, tight_row_dy(g, ty, f.tile_size)), ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, f.tile_size));
-                const uint32_t len = tight_row(g, ty, f.tile_size, inv_ts, f.nty, cw & 0xFFFFu, (cw >> 16) & 0x7FFFu, cw >> 31, cb, ca, r);
-                if (len) atomicAdd(&s_tcnt[j], len);
+                const uint32_t cw = s_tcol[j], rw = s_trow[j];
+                uint32_t w1, w2;
+                const uint32_t ilen = tight_slot_item(g, ri - s_trp[j], rw & 0xFFFFu, rw >> 16, f.tile_size, inv_ts, sub, inv_sub, ns, f.nty, cw & 0xFFFFu,
+                                                      (cw >> 16) & 0x7FFFu, cw >> 31, w1, w2);
+                if (ilen) {
+                    atomicAdd(&s_tcnt[j], ilen);
+                    atomicAdd(&s_rowhist[w1 & 0xFFu], 1u);
+                }
+                if (ok) {
+                    gs_row_u32x3 it;
+                    it.x = ilen ? s_tgid[j] : GS_ROW_HOLE; it.y = w1; it.z = w2;
+                    *reinterpret_cast<gs_row_u32x3*>(to.arena + (uint64_t)(abase + ri) * 3u) = it;
+                }
             }
             __syncthreads();
-            if (count) count = s_tcnt[tid];
+            if (count) count = ok ? s_tcnt[tid] : 0u;
+            rowptr = abase + myrp;
             if (!active) continue; // (after the last barrier of the trip)
         }
-        // low 22 bits: tile count; high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
+        // low 22 bits: tile count (TIGHT: row-item slots); high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
         const uint32_t bucket = f2u_sat(wg_min(50.0f * pv[2], 999.0f));
-        tile_counts[i] = count ? (count | (bucket << GS_COUNT_BITS)) : 0u;
-        if (FUSED) {
-            s_ecnt[v] = count;
-            s_eyb[v] = rminy | (bucket << 16);
-        }
-        if (count == 0) continue; // det == 0, or (slab mode) no instance in this rank's tile columns
+        tile_counts[i] = count ? ((TIGHT ? nslots : count) | (bucket << GS_COUNT_BITS)) : 0u;
+        if (count == 0) continue; // det == 0, no tile survives, or (slab mode) no instance in this rank's tile columns
+        if (TIGHT) to.rowptr[i] = rowptr;
 
         // ---- phase 3: colour (:240-280) and opacity (:282-294) ----
         float col[3];
-        sh_colour(rec, x, y, z, u, col);
+        sh_colour(s.sh + (uint64_t)i * 12, x, y, z, u, col);
         if (!TIGHT) opacity = sigmoid_ref(so.w);
         // GaussianData record (:97-104), 64 B as four 16-byte stores
         uint4* o4 = gdata + (uint64_t)i * 4;
@@ -426,90 +433,10 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         o4[2] = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[1]), __float_as_uint(col[2]), __float_as_uint(opacity));
         o4[3] = make_uint4(rminx, rminy, rmaxx, rmaxy);
     }
-    if (!FUSED) return;
-
-    // ---- scan of the workgroup's counts (survivor order = gaussian index order), look-back, emission ----
-    __syncthreads();
-    const uint32_t nblocks = (f.n + PRE_G - 1) / PRE_G;
-    const uint32_t c0 = (2 * tid < nvis) ? s_ecnt[2 * tid] : 0u, c1 = (2 * tid + 1 < nvis) ? s_ecnt[2 * tid + 1] : 0u;
-    const uint32_t pair = c0 + c1, pair_nz = (c0 != 0u) + (c1 != 0u);
-    const uint32_t incl = wave_incl_scan(pair, lane);
-    const uint32_t nzw = wave_sum(pair_nz);
-    if (lane == 63) s_misc[w] = incl;
-    if (lane == 0) s_misc[4 + w] = nzw;
-    __syncthreads();
-    uint32_t wave_excl = 0, block_total = 0, block_nz = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < (int)w) wave_excl += s_misc[k];
-        block_total += s_misc[k];
-        block_nz += s_misc[4 + k];
-    }
-    const uint32_t ex0 = wave_excl + incl - pair;
-    __syncthreads(); // s_misc is reused below; every thread has read its s_ecnt pair
-    if (2 * tid < nvis) s_ecnt[2 * tid] = ex0;
-    if (2 * tid + 1 < nvis) s_ecnt[2 * tid + 1] = ex0 + c0;
-    if (w == 0) {
-        const unsigned long long mine = ((unsigned long long)block_nz << 32) | (unsigned long long)block_total;
-        if (lane == 0) st_agent64(&status[bid], (bid == 0 ? PE_PREFIX : PE_AGG) | mine);
-        uint32_t excl = 0, excl_nz = 0;
-        if (bid > 0) {
-            int look = (int)bid - 1;
-            for (;;) {
-                const int idx = look - (int)lane;
-                unsigned long long sv = PE_PREFIX; // lanes before workgroup 0 contribute a zero prefix
-                if (idx >= 0) {
-                    uint32_t spins = 0;
-                    do {
-                        sv = ld_agent64(&status[idx]);
-                        if ((sv & PE_MASK) != 0) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    } while (++spins < GS_SPIN_LIMIT);
-                    if ((sv & PE_MASK) == 0) { ctl->fault = 1u; sv = PE_PREFIX; } // gave up: report, terminate the chain
-                }
-                const unsigned long long pmask = __ballot((sv & PE_MASK) == PE_PREFIX);
-                const uint32_t first = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-                excl += wave_sum((lane <= first) ? (uint32_t)sv : 0u);
-                excl_nz += wave_sum((lane <= first) ? (uint32_t)((sv & ~PE_MASK) >> 32) : 0u);
-                if (pmask) break;
-                look -= 64;
-            }
-        }
-        if (lane == 0) {
-            if (bid > 0)
-                st_agent64(&status[bid], PE_PREFIX | ((unsigned long long)(excl_nz + block_nz) << 32) | (unsigned long long)(excl + block_total));
-            s_misc[0] = excl;
-            if (bid == nblocks - 1) {
-                ctl->num_visible = excl_nz + block_nz;
-                ctl->num_intersections = excl + block_total;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t base_off = s_misc[0];
-    // instance e of the workgroup belongs to the last survivor v with prefix[v] <= e (zero-count survivors share
-    // their successor's prefix and are skipped by taking the last); y outer, x inner as write_tile_ids.wgsl:26-33
-    for (uint32_t e = tid; e < block_total; e += 256) {
-        uint32_t lo = 0;
-#pragma unroll
-        for (int step = 256; step >= 1; step >>= 1) {
-            const uint32_t mid = lo + step;
-            if (mid < nvis && s_ecnt[mid] <= e) lo = mid;
-        }
-        const uint32_t local = e - s_ecnt[lo];
-        const uint32_t r = s_erow[lo], y_b = s_eyb[lo];
-        const uint32_t xa = r & 0xFFFFu, wmain = (r >> 16) & 0x7FFFu, alias = r >> 31;
-        const uint32_t wtot = wmain + alias;
-        const uint32_t yy = local / wtot, xx = local - yy * wtot;
-        const uint32_t x = (xx < wmain) ? xa + xx : f.ntx;
-        const uint32_t y = (y_b & 0xFFFFu) + yy;
-        const uint32_t dst = base_off + e;
-        if (dst < f.capacity) {
-            keys[dst] = (y * f.ntx + x) * 1000u + (y_b >> 16);
-            values[dst] = base + s_ids[lo];
-        } else {
-            ctl->overflow = 1u;
-        }
+    if (TIGHT) { // the workgroup's items per tile row -> the row sort's digit histogram
+        __syncthreads();
+        const uint32_t c = s_rowhist[tid];
+        if (c) atomicAdd(&to.ctl->rowhist[tid], c);
     }
 }
 
@@ -519,35 +446,24 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
     const uint32_t blocks = (uint32_t)((total + 255) / 256);
     if (!blocks) return;
     hipLaunchKernelGGL(gs_repack_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)d_aos, n, (float*)s.px, (float*)s.py,
-                       (float*)s.pz, (float*)s.smax, (float*)s.rec);
+                       (float*)s.pz, (float*)s.smax, (float*)s.geo, (float*)s.sh);
 }
 // The projection's launch as data: the one kernel of a frame whose arguments change from frame to frame (the uniforms, by
 // value), so a captured frame graph (gs_runtime.hip) re-launches it with updated parameters.
 void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
-                           bool tight) {
-    // chunks per workgroup (see NB): 8 for a slab narrower than 30 % of the canvas, 4 up to 75 %, else 1
+                           bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl) {
+    // cull chunks per workgroup (see NB): tight path 8; else 8 for a slab narrower than 30 % of the canvas, 4 up to 75 %, else 1
     const uint32_t wcols = f.col1 - f.col0;
-    const uint32_t nb = f.full || wcols * 4u > f.ntx * 3u ? 1u : (wcols * 10u > f.ntx * 3u ? 4u : 8u);
+    const uint32_t nb = tight ? 8u : (f.full || wcols * 4u > f.ntx * 3u ? 1u : (wcols * 10u > f.ntx * 3u ? 4u : 8u));
     L.blocks = (f.n + PRE_G * nb - 1) / (PRE_G * nb);
-    if (tight) L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<false, true, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<false, true, 4>
-                                                                                                : (const void*)&gs_preprocess_kernel<false, true, 1>;
-    else L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<false, false, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<false, false, 4>
-                                                                                              : (const void*)&gs_preprocess_kernel<false, false, 1>;
+    if (tight) L.func = (const void*)&gs_preprocess_kernel<true, 8>;
+    else L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<false, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<false, 4>
+                                                                                        : (const void*)&gs_preprocess_kernel<false, 1>;
     L.s = s; L.u = u; L.f = f; L.gdata = gdata; L.counts = counts;
-    L.keys = nullptr; L.values = nullptr; L.status = nullptr; L.ticket = nullptr; L.ctl = nullptr;
-    L.args[0] = &L.s; L.args[1] = &L.u; L.args[2] = &L.f; L.args[3] = &L.gdata; L.args[4] = &L.counts; L.args[5] = &L.keys;
-    L.args[6] = &L.values; L.args[7] = &L.status; L.args[8] = &L.ticket; L.args[9] = &L.ctl;
+    L.to.arena = arena; L.to.rowptr = rowptr; L.to.ctl = ctl;
+    L.args[0] = &L.s; L.args[1] = &L.u; L.args[2] = &L.f; L.args[3] = &L.gdata; L.args[4] = &L.counts; L.args[5] = &L.to;
 }
 void gs_launch_preprocess(GsPreprocessLaunch& L, hipStream_t st) {
     if (!L.f.n) return;
     (void)hipLaunchKernel(L.func, dim3(L.blocks), dim3(256), L.args, 0, st);
-}
-uint32_t gs_project_emit_blocks(uint32_t n) { return (n + PRE_G - 1) / PRE_G; }
-// projection + scan + emission in one launch; status: gs_project_emit_blocks(n) zeroed 8-byte words, ticket: one zeroed word
-void gs_launch_project_emit(const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts, uint32_t* keys,
-                            uint32_t* values, unsigned long long* status, uint32_t* ticket, GsControl* ctl, hipStream_t st) {
-    const uint32_t blocks = gs_project_emit_blocks(f.n);
-    if (!blocks) return;
-    hipLaunchKernelGGL((gs_preprocess_kernel<true, false>), dim3(blocks), dim3(256), 0, st, s, u, f, (uint4*)gdata, counts, keys, values, status,
-                       ticket, ctl);
 }

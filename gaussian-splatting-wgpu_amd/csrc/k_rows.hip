@@ -1,0 +1,614 @@
+// k_rows.hip -- the tight row pipeline: from the projection's row items to the per-tile instance lists the blend walks.
+//
+// Replaces, on the product path (gs_render / gs_render_to with tight binning), write_tile_ids.wgsl::main (reference
+// src/write_tile_ids.wgsl:18-35), the instance passes of GPUSorter (src/radix_sort/sort.ts:249-350, radix_sort.wgsl:256-449) and
+// compute_ranges.wgsl::main (src/compute_ranges.wgsl:5-29).  gs_render_debug keeps the reference's stages (k_binning.hip,
+// k_sort.hip): every reference tap exists there.
+//
+// Round 2 emitted one (u16 tile, u32 value) pair per instance in depth order (instruction bound: the emission recomputed every
+// row's chords), moved all 18.4 M pairs through two look-back radix sweeps (latency bound) and read the sorted keys once more
+// for the ranges: 4 launches, 364 us at config B.  The observation behind this file: a gaussian's instances are, per tile row,
+// ONE run of consecutive tiles, so the unit that has to be ordered by tile ROW is the row item (7 M, not 18.4 M), and inside
+// one tile row the column is a digit of at most 8 bits.  Hence (MSD first):
+//   gs_rows_sort_kernel    the row items, gathered in depth order (slot_src, written by the gaussian-level sort), are
+//                          partitioned STABLY by tile row: one Onesweep-style pass (ticketed tiles, 4-byte look-back granules),
+//                          digit histogram = GsControl::rowhist, which the projection accumulated.
+//   gs_rows_count_kernel   chunks of 1024 consecutive items of ONE tile row count their instances per tile column (difference
+//                          array + scan) -> M3[chunk][column].
+//   gs_rows_scan_kernel    per tile row: prefix of M3 over the row's chunks (so no chunk ever waits for another), tile totals,
+//                          their prefix inside the row, the row's total.
+//   gs_rows_expand_kernel  every chunk expands its items into instances (value = gaussian id | sub-block mask << 28), ranks
+//                          them stably by column (wave ballots), reorders them through LDS and stores each column's run at
+//                          tile start + earlier chunks' count: the FINAL lists, written once, 4 bytes per instance; no key
+//                          is ever materialised, and `ranges` falls out of the scan.
+// Order inside a tile = item order inside the tile row = depth order of the gaussians = (bucket, index): the reference's.
+// Every kernel is integer work on 12-byte items and 4-byte values; algorithmic bytes per frame (R items, I instances):
+// 12 R (+4 R slot addresses) read + 12 R written by the row sort, 12 R read twice by count / expand, 4 I written.
+#include "gs_device.h"
+#include "gs_tight.h"
+
+typedef uint32_t gs_item3 __attribute__((ext_vector_type(3), aligned(4)));
+
+#define RA_ITEMS 12
+#define RA_WAVES 4
+#define RA_THREADS (RA_WAVES * 64)
+#define RA_TILE (RA_THREADS * RA_ITEMS) // 3072 slots per tile: 36 KB of LDS for the reorder, three workgroups per CU
+#define RA_AGG (1u << 30)
+#define RA_PREFIX (2u << 30)
+#define RA_FLAGS (3u << 30)
+#define RA_VALUE (~RA_FLAGS)
+
+#define RB_CH 1024u  // items per chunk
+#define RB_SB 4096u  // instances per sub-batch of the expansion (256 threads x 16)
+
+// ------------------------------------------------------------------------------------------------
+// Row sort: stable partition of the row items by tile row.
+// ------------------------------------------------------------------------------------------------
+struct RowSortShared {
+    uint32_t hist[RA_WAVES][256]; // per-wave digit counts -> exclusive offsets across waves -> + digit start
+    uint32_t gbase[256];          // global slot of position 0 of each digit's run, minus the digit's first position
+    uint32_t tot[256];
+    uint32_t dbase[256];          // exclusive scan of GsControl::rowhist
+    uint32_t wsum[RA_WAVES];
+    uint32_t tile, nvalid;
+    uint32_t it[RA_TILE * 3];
+};
+
+__global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t* __restrict__ arena, const uint32_t* __restrict__ slot_src,
+                                                                  uint32_t* __restrict__ rows_out, GsControl* ctl, uint32_t* __restrict__ status,
+                                                                  uint32_t row_cap) {
+    __shared__ RowSortShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t n = ctl->num_slots;
+    if (n > row_cap) n = row_cap;
+    const uint32_t ntiles = (n + RA_TILE - 1) / RA_TILE;
+    {   // first slot of every tile row's run: exclusive scan of the digit histogram (every workgroup for itself)
+        const uint32_t c = ctl->rowhist[tid];
+        const uint32_t incl = wave_incl_scan(c, lane);
+        if (lane == 63) sh.wsum[w] = incl;
+        __syncthreads();
+        uint32_t b = 0;
+        for (uint32_t k = 0; k < w; ++k) b += sh.wsum[k];
+        sh.dbase[tid] = b + incl - c;
+        __syncthreads();
+    }
+    for (;;) {
+        if (tid == 0) sh.tile = atomicAdd(&ctl->rows_ticket, 1u);
+        __syncthreads();
+        const uint32_t tile = sh.tile;
+        if (tile >= ntiles) break; // uniform
+        const uint32_t wbase = tile * RA_TILE + w * (64 * RA_ITEMS) + lane;
+        uint32_t ix[RA_ITEMS], iy[RA_ITEMS], iz[RA_ITEMS];
+        uint32_t rank2[RA_ITEMS / 2];
+#pragma unroll
+        for (int j = 0; j < RA_ITEMS; ++j) {
+            const uint32_t slot = wbase + j * 64;
+            ix[j] = GS_ROW_HOLE; iy[j] = 0u; iz[j] = 0u;
+            if (slot < n) {
+                const uint32_t src = slot_src[slot];
+                if (src < row_cap) {
+                    const gs_item3 v = *reinterpret_cast<const gs_item3*>(arena + (uint64_t)src * 3u);
+                    ix[j] = v.x; iy[j] = v.y; iz[j] = v.z;
+                }
+            }
+        }
+        for (uint32_t k = lane; k < 256; k += 64) sh.hist[w][k] = 0;
+        sh.tot[tid] = 0u;
+        __syncthreads();
+        // holes (and the slots past the end) take digit 255, which no tile row has (nty <= 255): they rank last and are not stored
+#pragma unroll
+        for (int j = 0; j < RA_ITEMS; ++j) atomicAdd(&sh.tot[ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu)], 1u);
+        __syncthreads();
+        // the tile's digit counts are published BEFORE the ranking: successors rarely meet an unpublished word
+        st_agent(status + (uint64_t)tile * 256 + tid, (tile == 0 ? RA_PREFIX : RA_AGG) | sh.tot[tid]);
+        // rank inside the wave: peers = lanes holding the same digit (8 ballots), order = (item, lane)
+#pragma unroll
+        for (int j = 0; j < RA_ITEMS; ++j) {
+            const uint32_t d = ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu);
+            uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit != 0u);
+                const uint32_t inv = bit - 1u;
+                plo &= (uint32_t)bal ^ inv;
+                phi &= (uint32_t)(bal >> 32) ^ inv;
+            }
+            const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
+            const uint32_t cnt = __popc(plo) + __popc(phi);
+            const uint32_t pre = sh.hist[w][d];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // every peer has read `pre` before the leader's store (one wave, in-order LDS)
+            if (below == 0) sh.hist[w][d] = pre + cnt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t r = pre + below;
+            if (j & 1) rank2[j >> 1] |= r << 16;
+            else rank2[j >> 1] = r;
+        }
+        __syncthreads();
+        // thread d: counts of digit d per wave -> exclusive offsets across waves, tile total; look-back over the predecessors
+        uint32_t cw[RA_WAVES], total = 0, excl = 0;
+#pragma unroll
+        for (int k = 0; k < RA_WAVES; ++k) { cw[k] = sh.hist[k][tid]; total += cw[k]; }
+        const uint32_t incl = wave_incl_scan(total, lane);
+        if (lane == 63) sh.wsum[w] = incl;
+        if (tile > 0) {
+            constexpr int LB = 8;
+            bool found = false;
+            for (int t = (int)tile - 1; t >= 0 && !found; t -= LB) {
+                uint32_t sv[LB];
+#pragma unroll
+                for (int k = 0; k < LB; ++k) sv[k] = (t - k >= 0) ? ld_agent(status + (uint64_t)(t - k) * 256 + tid) : RA_PREFIX;
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    if (found) break;
+                    uint32_t v = sv[k], spins = 0;
+                    while ((v & RA_FLAGS) == 0 && ++spins < GS_SPIN_LIMIT) { // not published yet: poll this one word
+                        __builtin_amdgcn_s_sleep(1);
+                        v = ld_agent(status + (uint64_t)(t - k) * 256 + tid);
+                    }
+                    if ((v & RA_FLAGS) == 0) { ctl->fault = 1u; found = true; break; }
+                    excl += v & RA_VALUE;
+                    if ((v & RA_FLAGS) == RA_PREFIX) found = true;
+                }
+            }
+            st_agent(status + (uint64_t)tile * 256 + tid, RA_PREFIX | ((excl + total) & RA_VALUE));
+        }
+        __syncthreads();
+        {
+            uint32_t wv = 0;
+            for (uint32_t k = 0; k < w; ++k) wv += sh.wsum[k];
+            uint32_t run = wv + incl - total; // first position of digit `tid` in the tile's sorted order
+            if (tid == 255u) sh.nvalid = run; // the holes start here
+            sh.gbase[tid] = sh.dbase[tid] + excl - run;
+#pragma unroll
+            for (int k = 0; k < RA_WAVES; ++k) { sh.hist[k][tid] = run; run += cw[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RA_ITEMS; ++j) {
+            const uint32_t d = ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu);
+            const uint32_t r = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
+            const uint32_t pos = sh.hist[w][d] + r;
+            sh.it[pos * 3 + 0] = ix[j];
+            sh.it[pos * 3 + 1] = iy[j];
+            sh.it[pos * 3 + 2] = iz[j];
+        }
+        __syncthreads();
+        const uint32_t nvalid = sh.nvalid;
+#pragma unroll
+        for (int j = 0; j < RA_ITEMS; ++j) {
+            const uint32_t pos = j * RA_THREADS + tid;
+            if (pos < nvalid) {
+                gs_item3 v;
+                v.x = sh.it[pos * 3 + 0]; v.y = sh.it[pos * 3 + 1]; v.z = sh.it[pos * 3 + 2];
+                const uint32_t g = sh.gbase[v.y & 0xFFu] + pos;
+                if (g < row_cap) *reinterpret_cast<gs_item3*>(rows_out + (uint64_t)g * 3u) = v;
+            }
+        }
+        __syncthreads(); // LDS is reused by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chunk geometry shared by the count / scan / expand kernels: tile row r holds items [ibase[r], ibase[r] + cnt[r]) of the
+// row-sorted array and chunks [cbase[r], cbase[r + 1]) of RB_CH items each (the last one shorter).
+// ------------------------------------------------------------------------------------------------
+struct RowTables {
+    uint32_t ibase[257]; // exclusive scan of GsControl::rowhist
+    uint32_t cbase[257]; // exclusive scan of ceil(rowhist / RB_CH)
+    uint32_t w4[8];
+};
+// 256 threads; leaves the tables valid after its last barrier
+__device__ __forceinline__ void row_tables(RowTables& T, const GsControl* ctl, uint32_t tid) {
+    const uint32_t lane = tid & 63, w = tid >> 6;
+    const uint32_t c = ctl->rowhist[tid], ch = (c + RB_CH - 1u) / RB_CH;
+    const uint32_t ic = wave_incl_scan(c, lane), ih = wave_incl_scan(ch, lane);
+    if (lane == 63) { T.w4[w] = ic; T.w4[4 + w] = ih; }
+    __syncthreads();
+    uint32_t bc = 0, bh = 0;
+    for (uint32_t k = 0; k < w; ++k) { bc += T.w4[k]; bh += T.w4[4 + k]; }
+    T.ibase[tid] = bc + ic - c;
+    T.cbase[tid] = bh + ih - ch;
+    if (tid == 255u) { T.ibase[256] = bc + ic; T.cbase[256] = bh + ih; }
+    __syncthreads();
+}
+// tile row of chunk c (c < cbase[256]): the LAST r with cbase[r] <= c (rows without chunks share their successor's base)
+__device__ __forceinline__ uint32_t row_of_chunk(const RowTables& T, uint32_t c) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        const uint32_t m = r + step;
+        if (m < 256u && T.cbase[m] <= c) r = m;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gs_rows_count_kernel(const uint32_t* __restrict__ rows, const GsControl* ctl, uint32_t* __restrict__ M3,
+                                                            uint32_t chunk_cap) {
+    __shared__ RowTables T;
+    __shared__ int s_diff[257];
+    __shared__ uint32_t s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    row_tables(T, ctl, tid);
+    uint32_t nch = T.cbase[256];
+    if (nch > chunk_cap) nch = chunk_cap;
+    for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        const uint32_t r = row_of_chunk(T, c);
+        const uint32_t i0 = T.ibase[r] + (c - T.cbase[r]) * RB_CH;
+        const uint32_t i1 = (i0 + RB_CH < T.ibase[r + 1]) ? i0 + RB_CH : T.ibase[r + 1];
+        s_diff[tid] = 0;
+        if (tid == 0) s_diff[256] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < (int)(RB_CH / 256u); ++k) {
+            const uint32_t i = i0 + k * 256u + tid;
+            if (i < i1) {
+                const uint32_t w1 = rows[(uint64_t)i * 3u + 1u];
+                const uint32_t tlo = (w1 >> 8) & 0xFFu, len = ((w1 >> 16) & 0xFFu) + 1u;
+                atomicAdd(&s_diff[tlo], 1);
+                atomicAdd(&s_diff[tlo + len > 256u ? 256u : tlo + len], -1);
+            }
+        }
+        __syncthreads();
+        // instances of column `tid` = inclusive prefix of the difference array
+        const uint32_t v = (uint32_t)s_diff[tid];
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t b = 0;
+        for (uint32_t k = 0; k < w; ++k) b += s_w[k];
+        M3[(uint64_t)c * 256u + tid] = b + incl;
+        __syncthreads();
+    }
+}
+
+// One workgroup of 1024 threads per tile row: thread (column c, part p) takes a quarter of the row's chunks.
+// tileoff[r * 256 + c] = instances of row r in columns < c; rowtot[r] = instances of the row (both saturate at 2^32 - 1).
+__global__ __launch_bounds__(1024) void gs_rows_scan_kernel(const GsControl* ctl, uint32_t* __restrict__ M3, uint32_t* __restrict__ tileoff,
+                                                            uint32_t* __restrict__ rowtot, uint32_t chunk_cap) {
+    __shared__ RowTables T;
+    __shared__ unsigned long long s_part[4][256];
+    __shared__ unsigned long long s_ex[256];
+    __shared__ unsigned long long s_w[4];
+    const uint32_t tid = threadIdx.x, c = tid & 255u, p = tid >> 8, r = blockIdx.x;
+    {
+        const uint32_t lane = tid & 63, w = tid >> 6;
+        uint32_t cc = 0, ch = 0;
+        if (tid < 256u) { cc = ctl->rowhist[tid]; ch = (cc + RB_CH - 1u) / RB_CH; }
+        const uint32_t ic = wave_incl_scan(cc, lane), ih = wave_incl_scan(ch, lane);
+        if (tid < 256u && lane == 63) { T.w4[w] = ic; T.w4[4 + w] = ih; }
+        __syncthreads();
+        if (tid < 256u) {
+            uint32_t bc = 0, bh = 0;
+            for (uint32_t k = 0; k < w; ++k) { bc += T.w4[k]; bh += T.w4[4 + k]; }
+            T.ibase[tid] = bc + ic - cc;
+            T.cbase[tid] = bh + ih - ch;
+            if (tid == 255u) { T.ibase[256] = bc + ic; T.cbase[256] = bh + ih; }
+        }
+        __syncthreads();
+    }
+    uint32_t c0 = T.cbase[r], c1 = T.cbase[r + 1];
+    if (c0 > chunk_cap) c0 = chunk_cap;
+    if (c1 > chunk_cap) c1 = chunk_cap;
+    const uint32_t nch = c1 - c0, per = (nch + 3u) / 4u;
+    const uint32_t j0 = c0 + (p * per < nch ? p * per : nch), j1 = c0 + ((p + 1u) * per < nch ? (p + 1u) * per : nch);
+    unsigned long long sum = 0;
+    for (uint32_t j = j0; j < j1; j += 8u) { // eight independent loads in flight
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (j + k < j1) ? M3[(uint64_t)(j + k) * 256u + c] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];
+    }
+    s_part[p][c] = sum;
+    __syncthreads();
+    unsigned long long run = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned long long t = s_part[k][c]; if (k < (int)p) run += t; tot += t; }
+    for (uint32_t j = j0; j < j1; j += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (j + k < j1) ? M3[(uint64_t)(j + k) * 256u + c] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (j + k < j1) M3[(uint64_t)(j + k) * 256u + c] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+            run += v[k];
+        }
+    }
+    // exclusive scan of the tile totals over the row's columns (threads of part 0)
+    if (p == 0) {
+        const uint32_t lane = tid & 63, w = tid >> 6;
+        unsigned long long incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = __shfl_up((uint32_t)incl, d, 64), hi = __shfl_up((uint32_t)(incl >> 32), d, 64);
+            if ((int)lane >= d) incl += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 63) s_w[w] = incl;
+        s_ex[c] = incl - tot; // in-wave exclusive
+    }
+    __syncthreads();
+    if (p == 0) {
+        const uint32_t w = tid >> 6;
+        unsigned long long b = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (k < (int)w) b += s_w[k]; all += s_w[k]; }
+        const unsigned long long ex = b + s_ex[c];
+        tileoff[r * 256u + c] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
+        if (c == 0) rowtot[r] = all > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)all;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Expansion: the final per-tile lists.
+// ------------------------------------------------------------------------------------------------
+struct ExpandShared {
+    RowTables T;
+    uint32_t rbase[257];      // first instance of every tile row in the lists (exclusive scan of rowtot, saturating)
+    uint32_t w0[RB_CH], w1[RB_CH], w2[RB_CH];
+    uint32_t hist[4][256];
+    uint32_t gbase[256];
+    uint32_t wsum[8];
+    uint32_t nvalid, total;
+    unsigned char cols[RB_SB];
+    union {                   // during the expansion: item prefix + owner marks; during the reorder: the sorted values
+        struct { uint32_t P[RB_CH + 1]; unsigned short mark[RB_SB]; } e;
+        uint32_t vals[RB_SB];
+    } x;
+};
+
+// sticky: see k_binning.hip fold_sticky (frames enqueued before the last one report their overflow / fault / size here)
+__global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __restrict__ rows, GsControl* ctl, const uint32_t* __restrict__ M3,
+                                                             const uint32_t* __restrict__ tileoff, const uint32_t* __restrict__ rowtot, GsFrame f,
+                                                             uint32_t* __restrict__ values, uint32_t* __restrict__ ranges, uint32_t chunk_cap,
+                                                             uint32_t* sticky) {
+    __shared__ ExpandShared S;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t ns = f.tile_size >= 16u ? 2u : 1u;
+    row_tables(S.T, ctl, tid);
+    {   // first instance of every tile row
+        const uint32_t v = tid < f.nty ? rowtot[tid] : 0u;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = __shfl_up((uint32_t)incl, d, 64), hi = __shfl_up((uint32_t)(incl >> 32), d, 64);
+            if ((int)lane >= d) incl += ((unsigned long long)hi << 32) | lo;
+        }
+        __shared__ unsigned long long s_r[4];
+        if (lane == 63) s_r[w] = incl;
+        __syncthreads();
+        unsigned long long b = 0;
+        for (uint32_t k = 0; k < w; ++k) b += s_r[k];
+        const unsigned long long ex = b + incl - v;
+        S.rbase[tid] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
+        if (tid == 255u) S.rbase[256] = (b + incl) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(b + incl);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) { // the frame's instance count; overflow / fault / size folded into the sticky words
+        const uint32_t I = S.rbase[256];
+        ctl->num_intersections = I;
+        ctl->num_items = S.T.ibase[256];
+        const bool over = I > f.capacity || ctl->overflow;
+        if (I > f.capacity) ctl->overflow = 1u;
+        if (sticky) {
+            uint32_t need = 0; // arena slots this frame would have needed: 16 shards as large as the fullest one
+            for (int k = 0; k < 16; ++k) need = ctl->row_cursor[k] > need ? ctl->row_cursor[k] : need;
+            need = need > 0x07FFFFFFu ? 0x7FFFFFFFu : need * 16u;
+            if (over) atomicAdd(&sticky[0], 1u);
+            if (ctl->fault) atomicOr(&sticky[1], 1u);
+            atomicMax(&sticky[2], I);
+            atomicMax(&sticky[3], need);
+        }
+    }
+    // ranges[t] = end of tile t's list (compute_ranges.wgsl:5-29): workgroup r writes tile row r
+    for (uint32_t r = blockIdx.x; r < f.nty; r += gridDim.x) {
+        if (tid < f.ntx) {
+            const uint32_t endoff = (tid + 1u < 256u) ? tileoff[r * 256u + tid + 1u] : rowtot[r];
+            const unsigned long long e = (unsigned long long)S.rbase[r] + endoff;
+            ranges[r * f.ntx + tid] = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+        }
+    }
+    uint32_t nch = S.T.cbase[256];
+    if (nch > chunk_cap) nch = chunk_cap;
+    for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        const uint32_t r = row_of_chunk(S.T, c);
+        const uint32_t i0 = S.T.ibase[r] + (c - S.T.cbase[r]) * RB_CH;
+        const uint32_t i1 = (i0 + RB_CH < S.T.ibase[r + 1]) ? i0 + RB_CH : S.T.ibase[r + 1];
+        const uint32_t ni = i1 - i0;
+        // ---- the chunk's items (thread t: items 4t .. 4t+3, consecutive) and the prefix of their lengths ----
+        uint32_t len[4], lsum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = tid * 4u + k;
+            len[k] = 0u;
+            if (e < ni) {
+                const gs_item3 v = *reinterpret_cast<const gs_item3*>(rows + (uint64_t)(i0 + e) * 3u);
+                S.w0[e] = v.x; S.w1[e] = v.y; S.w2[e] = v.z;
+                len[k] = ((v.y >> 16) & 0xFFu) + 1u;
+            }
+            lsum += len[k];
+        }
+        {
+            const uint32_t incl = wave_incl_scan(lsum, lane);
+            if (lane == 63) S.wsum[w] = incl;
+            __syncthreads();
+            uint32_t b = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (k < (int)w) b += S.wsum[k]; all += S.wsum[k]; }
+            uint32_t run = b + incl - lsum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { S.x.e.P[tid * 4u + k] = run; run += len[k]; }
+            if (tid == 0) { S.x.e.P[RB_CH] = all; S.total = all; }
+        }
+        // first list slot of column `tid` for this chunk: tile start + what the row's earlier chunks put there
+        const uint32_t tstart = S.rbase[r] + tileoff[r * 256u + tid];
+        uint32_t done = M3[(uint64_t)c * 256u + tid];
+        __syncthreads();
+        const uint32_t ninst = S.total;
+        for (uint32_t s0 = 0; s0 < ninst; s0 += RB_SB) {
+            // ---- owner marks: an item whose first instance falls into the sub-batch marks that slot ----
+            if (s0) {
+                __syncthreads(); // the previous sub-batch's stores have read x.vals: P / mark are rebuilt (P from the items kept in LDS)
+                uint32_t l2[4], ls = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const uint32_t e = tid * 4u + k; l2[k] = e < ni ? ((S.w1[e] >> 16) & 0xFFu) + 1u : 0u; ls += l2[k]; }
+                const uint32_t incl = wave_incl_scan(ls, lane);
+                if (lane == 63) S.wsum[w] = incl;
+                __syncthreads();
+                uint32_t b = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < (int)w) b += S.wsum[k];
+                uint32_t run = b + incl - ls;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { S.x.e.P[tid * 4u + k] = run; run += l2[k]; }
+                if (tid == 0) S.x.e.P[RB_CH] = ninst;
+            }
+            for (uint32_t k = tid; k < RB_SB / 2u; k += 256u) reinterpret_cast<uint32_t*>(S.x.e.mark)[k] = 0u;
+            for (uint32_t k = lane; k < 256; k += 64) S.hist[w][k] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = tid * 4u + k;
+                if (e < ni) {
+                    const uint32_t p0 = S.x.e.P[e];
+                    if (p0 >= s0 && p0 < s0 + RB_SB) S.x.e.mark[p0 - s0] = (unsigned short)(e + 1u);
+                }
+            }
+            __syncthreads();
+            // ---- expansion: thread slot (w, j, lane) = instance s0 + w*1024 + j*64 + lane ----
+            // owner of the wave's first slot: the last item whose prefix is <= it
+            uint32_t carry;
+            {
+                const uint32_t x0 = s0 + w * 1024u;
+                uint32_t e = 0;
+#pragma unroll
+                for (int step = 512; step >= 1; step >>= 1) {
+                    const uint32_t m = e + step;
+                    if (m < ni && S.x.e.P[m] <= x0) e = m;
+                }
+                carry = e + 1u;
+            }
+            uint32_t val[16], col4[4] = {0u, 0u, 0u, 0u};
+            uint32_t rank2[8];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t sp = w * 1024u + j * 64u + lane, x = s0 + sp;
+                uint32_t m = wave_incl_max((uint32_t)S.x.e.mark[sp]);
+                m = m > carry ? m : carry;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+                uint32_t d = 255u;
+                val[j] = 0u;
+                if (x < ninst) {
+                    const uint32_t e = m - 1u;
+                    const uint32_t q = x - S.x.e.P[e], i1w = S.w1[e];
+                    d = ((i1w >> 8) & 0xFFu) + q;
+                    val[j] = (S.w0[e] & GS_ID_MASK) | (tight_item_mask(S.w2[e], q, ns) << GS_ID_BITS);
+                }
+                col4[j >> 2] |= d << (8 * (j & 3));
+            }
+            // ---- rank by column inside the wave (slots past the end take digit 255: no tile column has it, ntx <= 255) ----
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t d = (col4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit != 0u);
+                    const uint32_t inv = bit - 1u;
+                    plo &= (uint32_t)bal ^ inv;
+                    phi &= (uint32_t)(bal >> 32) ^ inv;
+                }
+                const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
+                const uint32_t cnt = __popc(plo) + __popc(phi);
+                const uint32_t pre = S.hist[w][d];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (below == 0) S.hist[w][d] = pre + cnt;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t rr = pre + below;
+                if (j & 1) rank2[j >> 1] |= rr << 16;
+                else rank2[j >> 1] = rr;
+            }
+            __syncthreads(); // (also: every wave is done with P / mark, which the sorted values overwrite below)
+            // ---- thread = column: exclusive offsets across waves, start of the column's run in the sub-batch's sorted order ----
+            {
+                uint32_t cw[4], total = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { cw[k] = S.hist[k][tid]; total += cw[k]; }
+                const uint32_t incl = wave_incl_scan(total, lane);
+                if (lane == 63) S.wsum[4 + w] = incl;
+                __syncthreads();
+                uint32_t b = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < (int)w) b += S.wsum[4 + k];
+                uint32_t run = b + incl - total;
+                if (tid == 255u) S.nvalid = run;
+                S.gbase[tid] = tstart + done - run; // (wraps are harmless: only gbase + position is used, and it is bounds-checked)
+                done += total;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { S.hist[k][tid] = run; run += cw[k]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t d = (col4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t rr = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
+                const uint32_t pos = S.hist[w][d] + rr;
+                S.x.vals[pos] = val[j];
+                S.cols[pos] = (unsigned char)d;
+            }
+            __syncthreads();
+            const uint32_t nvalid = S.nvalid;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t pos = j * 256u + tid;
+                if (pos < nvalid) {
+                    const uint32_t dst = S.gbase[S.cols[pos]] + pos;
+                    if (dst < f.capacity) values[dst] = S.x.vals[pos];
+                }
+            }
+        }
+        __syncthreads(); // the items / tables of the next chunk overwrite LDS
+    }
+}
+
+// GS_BUF_KEYS tap of a tight frame: key = tile * 1000 + depth bucket of the gaussian (write_tile_ids.wgsl:31); the tile of list
+// entry j is found in `ranges`, the bucket in the high bits of the gaussian's count word.
+__global__ __launch_bounds__(256) void gs_rows_rebuild_keys_kernel(const uint32_t* __restrict__ ranges, uint32_t T, const uint32_t* __restrict__ vals,
+                                                                   const uint32_t* __restrict__ counts, uint32_t count, uint32_t n,
+                                                                   uint32_t* __restrict__ keys) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        uint32_t lo = 0, hi = T; // first tile whose end is > i
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ranges[mid] > i) hi = mid; else lo = mid + 1u;
+        }
+        const uint32_t g = vals[i] & GS_ID_MASK;
+        keys[i] = lo * 1000u + (g < n ? counts[g] >> GS_COUNT_BITS : 0u);
+    }
+}
+
+// ---- host launchers --------------------------------------------------------------------------------
+uint32_t gs_rows_sort_tiles(uint64_t row_cap) { return (uint32_t)((row_cap + RA_TILE - 1) / RA_TILE); }
+uint32_t gs_rows_chunks(uint64_t row_cap) { return (uint32_t)(row_cap / RB_CH + 256u); }
+// cus: compute units (grids are sized by residency: three workgroups of the sort / the expansion fit a CU, eight of the count)
+void gs_launch_rows(const uint32_t* arena, const uint32_t* slot_src, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
+                    uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
+                    uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg) {
+    const uint32_t chunk_cap = gs_rows_chunks(row_cap);
+    if (!cus) cus = 1;
+    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, slot_src, rows_sorted, ctl, sort_status, row_cap);
+    if (mark) mark(mark_arg, 3);
+    hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * 8u), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
+    hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap);
+    hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * 3u), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
+                       (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, sticky);
+}
+void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,
+                                 uint32_t* keys, hipStream_t st) {
+    if (!count) return;
+    const uint32_t blocks = (count + 255u) / 256u;
+    hipLaunchKernelGGL(gs_rows_rebuild_keys_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, ranges, T, vals, counts, count, n, keys);
+}

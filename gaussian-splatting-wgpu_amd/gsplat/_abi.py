@@ -52,7 +52,8 @@ class GsStats(ctypes.Structure):
                 ("frames", ctypes.c_uint64), ("stage_us", ctypes.c_float * 6), ("frame_us", ctypes.c_float),
                 ("stage_us_mean", ctypes.c_float * 6), ("frame_us_mean", ctypes.c_float), ("frames_timed", ctypes.c_uint32), ("depth_ordered", ctypes.c_uint32), ("num_evaluated", ctypes.c_uint64),
                 ("capacity", ctypes.c_uint64), ("max_intersections_seen", ctypes.c_uint64), ("truncated_frames", ctypes.c_uint64),
-                ("tight_binning", ctypes.c_uint32), ("frames_in_flight", ctypes.c_uint32), ("graph_frames", ctypes.c_uint64)]
+                ("tight_binning", ctypes.c_uint32), ("frames_in_flight", ctypes.c_uint32), ("graph_frames", ctypes.c_uint64),
+                ("num_row_items", ctypes.c_uint64), ("num_row_slots", ctypes.c_uint64), ("row_capacity", ctypes.c_uint64)]
 
 
 class GsError(RuntimeError):

@@ -149,7 +149,8 @@ class Renderer:
         check(self._L.gs_get_stats(self._ctx, ctypes.byref(s)))
         d = {k: getattr(s, k) for k in ("num_gaussians", "num_visible", "num_intersections", "num_processed", "num_tiles",
                                         "sort_passes", "frames", "frame_us", "frame_us_mean", "frames_timed", "num_evaluated", "depth_ordered",
-                                        "capacity", "max_intersections_seen", "truncated_frames", "tight_binning", "frames_in_flight", "graph_frames")}
+                                        "capacity", "max_intersections_seen", "truncated_frames", "tight_binning", "frames_in_flight", "graph_frames",
+                                        "num_row_items", "num_row_slots", "row_capacity")}
         d["stage_us"] = {n: s.stage_us[i] for i, n in enumerate(_abi.GS_STAGE_NAMES)}
         d["stage_us_mean"] = {n: s.stage_us_mean[i] for i, n in enumerate(_abi.GS_STAGE_NAMES)}
         self.numIntersections = d["num_intersections"]

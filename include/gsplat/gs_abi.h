@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 /* ---- status codes (every function returns one; message via gs_last_error) ------------------ */
 #define GS_OK 0
@@ -105,6 +105,9 @@ typedef struct gs_stats {
                                      instance lists are then a subset of the reference's (GS_OPT_TILE_CULL)             */
     uint32_t frames_in_flight;    /* contexts of the ring gs_render alternates between now (GS_OPT_FRAMES_IN_FLIGHT)      */
     uint64_t graph_frames;        /* frames replayed from the captured frame graph (GS_OPT_FRAME_GRAPH), summed over the ring */
+    uint64_t num_row_items;       /* tight frames (ABI 3): row items = (gaussian, tile row) runs of tiles the lists were expanded from */
+    uint64_t num_row_slots;       /*   ... slots reserved for them (items + rows that turned out empty)                               */
+    uint64_t row_capacity;        /* row-item slots the context holds now (grown like `capacity`)                                  */
 } gs_stats;
 
 /* ---- debug taps: the buffers the reference author inspected by hand (renderer.ts:423-438,504-519) */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libgsplat_hip.so does not export %s" % n
     assert sorted(_abi.ABI_SYMBOLS) == names
-    assert L.gs_abi_version() == 2
+    assert L.gs_abi_version() == 3
 
 
 def test_struct_layouts_match_header(tmp_path):

@@ -28,14 +28,17 @@ def test_frame_exact_mode(oracle, n, W, H, ts):
     r.render_uniforms(u)  # the product path (no debug copies, no gdata clear)
     r.wait()
     _check_stages(r, ref, exact_image=True, debug=False)
-    r.set_option(_abi.GS_OPT_UNFUSED, 0)  # experimental: projection + scan + emission fused in one launch
+    r.set_option(_abi.GS_OPT_TILE_CULL, 0)  # product frames with the reference's binning, in both emission orders
+    for order in (1, 0):  # gaussian-index order + full-key sort; depth-ordered emission + tile-only instance sort
+        r.set_option(_abi.GS_OPT_EMIT_ORDER, order)
+        r.render_uniforms(u)
+        r.wait()
+        assert r.stats()["tight_binning"] == 0 and r.stats()["depth_ordered"] == (1 - order)
+        _check_stages(r, ref, exact_image=True, debug=False)
+    r.set_option(_abi.GS_OPT_TILE_CULL, 1)  # back to the tight row pipeline: same image, subset lists
     r.render_uniforms(u)
     r.wait()
-    _check_stages(r, ref, exact_image=True, debug=False)
-    r.set_option(_abi.GS_OPT_UNFUSED, 1)
-    r.set_option(_abi.GS_OPT_EMIT_ORDER, 0)  # depth-ordered emission, tile-only instance sort (auto-selected for big frames)
-    r.render_uniforms(u)
-    r.wait()
+    assert r.stats()["tight_binning"] == 1
     _check_stages(r, ref, exact_image=True, debug=False)
     r.destroy()
 

@@ -11,6 +11,7 @@
 #define __device__
 #define __forceinline__ inline
 #define __builtin_amdgcn_logf(x) log2f(x)
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #include "gs_tight_host.h" // = gs_tight.h without its gs_device.h include (made by run.py)
 
 static std::vector<uint32_t> rd(const char* p) {
@@ -47,33 +48,22 @@ int main(int argc, char** argv) {
             const uint32_t cnt = tight_count(tg, ry0, ry1, ts, inv_ts, nty, xa, wmain, alias);
             uint32_t got = 0;
             if (tg.mode != 0) {
+                // through the row items of the tight row pipeline (gs_tight.h: tight_slot_item / tight_item_mask)
                 uint32_t ra, rb;
                 tight_rows(tg, ry0, ry1, ts, inv_ts, nty, alias, ra, rb);
-                for (uint32_t ty = ra; ty < rb; ++ty) {
-                    TightRow r;
-                    const TightChord cb = tight_chord_at(tg, tight_row_dy(tg, ty, ts)), ca = tight_chord_at(tg, tight_row_dy(tg, ty + 1, ts));
-                    got += tight_row(tg, ty, ts, inv_ts, nty, xa, wmain, alias, cb, ca, r);
-                    if (r.thi >= r.tlo) {
-                        int lo[2], hi2[2];
-                        const int cmin = r.tlo * (int)ns, cmax = (r.thi + 1) * (int)ns - 1;
-                        tight_substrips(tg, ty, ts, sub, inv_sub, cmin, cmax, cb, ca, lo, hi2);
-                        for (int tc = r.tlo; tc <= r.thi; ++tc) {
-                            uint32_t m;
-                            if (ns == 2) {
-                                const int c0 = 2 * tc, c1 = c0 + 1;
-                                m = (lo[0] <= c0 && c0 <= hi2[0]) | ((lo[0] <= c1 && c1 <= hi2[0]) << 1) | ((lo[1] <= c0 && c0 <= hi2[1]) << 2) |
-                                    ((lo[1] <= c1 && c1 <= hi2[1]) << 3);
-                            } else m = (lo[0] <= tc && tc <= hi2[0]);
-                            sets[g][ty * ntx + tc] |= 0x100 | m;
-                        }
-                    }
-                    if (r.alias) {
-                        int lo[2], hi2[2];
-                        const TightChord c2 = tight_chord_at(tg, tight_row_dy(tg, ty + 2, ts));
-                        tight_substrips(tg, ty + 1, ts, sub, inv_sub, 0, (int)ns - 1, ca, c2, lo, hi2);
-                        uint32_t am = (lo[0] <= 0 && 0 <= hi2[0]);
-                        if (ns == 2) am |= ((lo[0] <= 1 && 1 <= hi2[0]) << 1) | ((lo[1] <= 0 && 0 <= hi2[1]) << 2) | ((lo[1] <= 1 && 1 <= hi2[1]) << 3);
-                        sets[g][ty * ntx + ntx] |= 0x100 | am;
+                const uint32_t nrows = rb - ra, nslots = nrows * (1 + alias);
+                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                    uint32_t w1, w2;
+                    const uint32_t len = tight_slot_item(tg, sl, ra, nrows, ts, inv_ts, sub, inv_sub, ns, nty, xa, wmain, alias, w1, w2);
+                    got += len;
+                    if (!len) continue;
+                    const uint32_t trow = w1 & 0xFF, tlo = (w1 >> 8) & 0xFF, l2 = ((w1 >> 16) & 0xFF) + 1;
+                    if (l2 != len) { printf("len mismatch\n"); return 1; }
+                    for (uint32_t q = 0; q < len; ++q) {
+                        const uint32_t m = tight_item_mask(w2, q, ns);
+                        // an aliased item is recorded under the key tile it carries in the reference: (row - 1) * ntx + ntx
+                        const uint32_t tile = trow * ntx + tlo + q;
+                        sets[g][tile] |= 0x100 | m;
                     }
                 }
             }
