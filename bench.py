@@ -251,6 +251,7 @@ def main():
                          "are measured")
     ap.add_argument("--ply", default=os.environ.get("GS_PLY", ""),
                     help="render this 3DGS .ply (native loader) instead of the synthetic scene; also taken from $GS_PLY (SURVEY.md 8d)")
+    ap.add_argument("--proj-chunks", type=int, default=0, help="GS_OPT_PROJ_CHUNKS (tuning): cull chunks per workgroup of the tight projection")
     ap.add_argument("--lib", default="", help="A/B only: another build of libgsplat_hip.so (sets $GSPLAT_LIB)")
     args = ap.parse_args()
     if args.lib:
@@ -327,6 +328,8 @@ def main():
             rr.set_option(_abi.GS_OPT_BLEND_ABLATION, args.blend_ablation)
         if args.graph >= 0:
             rr.set_option(_abi.GS_OPT_FRAME_GRAPH, args.graph)
+        if args.proj_chunks:
+            rr.set_option(_abi.GS_OPT_PROJ_CHUNKS, args.proj_chunks)
 
     options(r)
     if args.frames_in_flight > 0 and not multi:

@@ -43,8 +43,15 @@ struct GsControl {
     unsigned long long num_processed[64]; // blend: staged list entries (64 partial sums)
     unsigned long long num_evaluated[64]; // blend: (wave, entry) pairs that survived the 8x8 cull
     uint32_t hist[4][256];    // instance sort: digit histograms -> exclusive digit bases
-    uint32_t rowhist[256];    // row sort: items per tile row (accumulated by the tight projection)
+    uint32_t rowhist[8][256]; // row sort: items per tile row, accumulated by the tight projection in 8 copies (workgroup % 8:
+                              // one word would take every workgroup's atomic); readers add the copies up (gs_rowhist)
 };
+__device__ __forceinline__ uint32_t gs_rowhist(const GsControl* ctl, uint32_t r) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += ctl->rowhist[k][r];
+    return s;
+}
 
 struct GsTightOut { // product-path outputs of the tight projection beside GaussianData and the count words (k_preprocess.hip)
     uint32_t* arena; uint32_t* rowptr; GsControl* ctl;

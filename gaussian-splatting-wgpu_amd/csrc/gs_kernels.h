@@ -11,16 +11,15 @@ struct GsPreprocessLaunch { // the projection's launch as data (its uniforms are
     void* args[6];
 };
 void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
-                           bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl);
+                           bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl, uint32_t tight_nb = 0);
 void gs_launch_preprocess(GsPreprocessLaunch& L, hipStream_t st);
 uint32_t gs_scan_blocks(uint32_t n);
 void gs_launch_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, unsigned long long* status, uint32_t* ticket, GsControl* ctl,
                     hipStream_t st);
 uint64_t gs_emit_chunks(uint64_t capacity);
-// counts: tile-count words in the SAME order as offsets/perm (sorted order)
-void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
-                             const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
-                             uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st);
+// grec: the gaussian-level sort's records {id, count word, first output slot, -} in (bucket, index) order
+void gs_launch_emit_balanced(const void* gdata, const void* grec, const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values,
+                             GsControl* ctl, uint32_t grid, uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st);
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
@@ -43,13 +42,12 @@ void gs_launch_assemble(const void* slabs, void* image, uint32_t width, uint32_t
 // k_gsort.hip: the visible gaussians sorted by depth bucket (stable) with their quantity (tile count / row-item slots) scanned in that order
 uint32_t gs_gsort_tiles(uint32_t n);
 uint64_t gs_gsort_scratch_bytes(uint32_t n);
-void gs_launch_gsort(const uint32_t* words, const uint32_t* aux_in, uint32_t n, void* scratch, uint32_t* perm, uint32_t* scounts, uint32_t* offsets,
-                     uint32_t* chunk_table, uint32_t chunk_cap, uint32_t* slot_src, uint32_t slot_cap, uint32_t* tot_visible,
-                     uint32_t* tot_quantity, hipStream_t st);
+void gs_launch_gsort(const uint32_t* words, const uint32_t* aux_in, uint32_t n, void* scratch, void* grec, uint32_t* chunk_table, uint32_t chunk_cap,
+                     uint32_t* tot_visible, uint32_t* tot_quantity, hipStream_t st);
 // k_rows.hip: the tight row pipeline (row sort, per-chunk counts, scan, expansion into the final per-tile lists + ranges)
 uint32_t gs_rows_sort_tiles(uint64_t row_cap);
 uint32_t gs_rows_chunks(uint64_t row_cap);
-void gs_launch_rows(const uint32_t* arena, const uint32_t* slot_src, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
+void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chunk_table, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
                     uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
                     uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg);
 void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,

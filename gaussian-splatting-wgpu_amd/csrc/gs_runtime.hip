@@ -117,12 +117,12 @@ struct gs_ctx {
     uint32_t* tile_depth = nullptr;             // blend statistic: deepest staged entry per tile (quadrant kernel)
     uint32_t* sort_status = nullptr;            // instance sort (reference binning)
     uint32_t* rows_status = nullptr;            // row sort (tight row pipeline)
-    uint32_t* perm = nullptr;                   // visible gaussians in (depth bucket, index) order (k_gsort.hip)
-    uint32_t* scounts = nullptr;                // their count words in that order
+    void* grec = nullptr;                       // visible gaussians in (depth bucket, index) order: {id, count word, prefix, arena address} (k_gsort.hip)
+    uint32_t tight_nb = 0;                      // GS_OPT_PROJ_CHUNKS: cull chunks per workgroup of the tight projection (0 = automatic)
     void* gsort_scratch = nullptr;              // (bucket, chunk) table of the gaussian-level counting sort
     // tight row pipeline (k_rows.hip): row items in projection order / sorted by tile row, slot addresses in depth order
     uint64_t row_cap = 0;
-    uint32_t *arena = nullptr, *rows_sorted = nullptr, *slot_src = nullptr, *rowptr = nullptr;
+    uint32_t *arena = nullptr, *rows_sorted = nullptr, *rowptr = nullptr;
     uint32_t *M3 = nullptr, *tileoff = nullptr, *rowtot = nullptr;
     bool tight_ok = false;                      // the canvas has at most 255 tile rows and columns (8-bit digits of the row pipeline)
     bool scene_borrowed = false;                // gs_share_splats: scene_mem belongs to another context
@@ -176,9 +176,9 @@ GS_EXPORT int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
 static void free_kv(gs_ctx* c) {
     hipFree(c->keysA); hipFree(c->valsA); hipFree(c->keysB); hipFree(c->valsB); hipFree(c->keysU); hipFree(c->valsU);
     hipFree(c->ctl_mem); hipFree(c->chunk_table); hipFree(c->keysG);
-    hipFree(c->arena); hipFree(c->rows_sorted); hipFree(c->slot_src); hipFree(c->M3);
+    hipFree(c->arena); hipFree(c->rows_sorted); hipFree(c->M3);
     c->keysA = c->valsA = c->keysB = c->valsB = c->keysU = c->valsU = c->keysG = nullptr;
-    c->arena = c->rows_sorted = c->slot_src = c->M3 = nullptr;
+    c->arena = c->rows_sorted = c->M3 = nullptr;
     c->keysG_valid = false;
     c->chunk_table = nullptr;
     c->ctl_mem = nullptr;
@@ -197,11 +197,10 @@ static int32_t alloc_kv(gs_ctx* c, uint64_t capacity, uint64_t row_cap) {
     HIP_TRY(hipMalloc((void**)&c->valsA, kb));
     HIP_TRY(hipMalloc((void**)&c->keysB, kb));
     HIP_TRY(hipMalloc((void**)&c->valsB, kb));
-    HIP_TRY(hipMalloc((void**)&c->chunk_table, (size_t)gs_emit_chunks(capacity) * 4));
+    HIP_TRY(hipMalloc((void**)&c->chunk_table, (size_t)gs_emit_chunks(std::max(capacity, row_cap)) * 4));
     if (c->tight_ok) {
         HIP_TRY(hipMalloc((void**)&c->arena, (size_t)row_cap * 12));
         HIP_TRY(hipMalloc((void**)&c->rows_sorted, (size_t)row_cap * 12));
-        HIP_TRY(hipMalloc((void**)&c->slot_src, (size_t)row_cap * 4));
         HIP_TRY(hipMalloc((void**)&c->M3, (size_t)gs_rows_chunks(row_cap) * 256 * 4));
     }
     const size_t ctl_sz = (sizeof(GsControl) + 255) & ~(size_t)255;
@@ -305,7 +304,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     free_kv(c);
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->perm); hipFree(c->rowptr); hipFree(c->scounts); hipFree(c->gsort_scratch);
+    hipFree(c->grec); hipFree(c->rowptr); hipFree(c->gsort_scratch);
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky); hipFree(c->blend_prof);
     hipFree(c->tileoff); hipFree(c->rowtot);
     if (c->h_ctl) hipHostFree(c->h_ctl);
@@ -325,10 +324,10 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity =
     c->graph_valid = false;
     if (!c->scene_borrowed) hipFree(c->scene_mem);
     hipFree(c->counts); hipFree(c->offsets); hipFree(c->gdata);
-    hipFree(c->perm); hipFree(c->rowptr); hipFree(c->scounts); hipFree(c->gsort_scratch);
-    c->scounts = nullptr; c->gsort_scratch = nullptr;
+    hipFree(c->grec); hipFree(c->rowptr); hipFree(c->gsort_scratch);
+    c->grec = nullptr; c->gsort_scratch = nullptr;
     c->scene_mem = nullptr; c->counts = nullptr; c->offsets = nullptr; c->gdata = nullptr;
-    c->perm = c->rowptr = nullptr;
+    c->rowptr = nullptr;
     c->scene_borrowed = false;
     c->n = (uint32_t)n;
     c->frame.n = (uint32_t)n;
@@ -336,9 +335,8 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity =
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
     HIP_TRY(hipMalloc((void**)&c->counts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc((void**)&c->offsets, std::max<size_t>(np * 4, 256)));
-    HIP_TRY(hipMalloc((void**)&c->perm, std::max<size_t>(np * 4, 256)));
+    HIP_TRY(hipMalloc(&c->grec, std::max<size_t>(np * 16, 256)));
     HIP_TRY(hipMalloc((void**)&c->rowptr, std::max<size_t>(np * 4, 256)));
-    HIP_TRY(hipMalloc((void**)&c->scounts, std::max<size_t>(np * 4, 256)));
     HIP_TRY(hipMalloc(&c->gsort_scratch, gs_gsort_scratch_bytes((uint32_t)n)));
     HIP_TRY(hipMalloc(&c->gdata, std::max<size_t>((size_t)n * 64, 256)));
     HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)n * 64, 256), c->stream));
@@ -442,7 +440,7 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
     HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
-    gs_preprocess_prepare(c->pre, c->scene, u, f, c->gdata, c->counts, tight, c->arena, c->rowptr, c->ctl);
+    gs_preprocess_prepare(c->pre, c->scene, u, f, c->gdata, c->counts, tight, c->arena, c->rowptr, c->ctl, c->tight_nb);
     gs_launch_preprocess(c->pre, st);
     mark(c, 1);
     const bool by_index = !tight && (debug || c->index_order);
@@ -451,10 +449,10 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
         // The tight row pipeline (k_rows.hip).  Stage brackets: "scan" = the gaussian-level sort by depth bucket, "emit" = the
         // row sort (the row items take write_tile_ids' place), "sort" = count + scan + expansion into the final lists,
         // "ranges" = nothing (they fall out of the scan).
-        gs_launch_gsort(c->counts, c->rowptr, c->n, c->gsort_scratch, c->perm, c->scounts, c->offsets, nullptr, 0u, c->slot_src, (uint32_t)c->row_cap,
+        gs_launch_gsort(c->counts, c->rowptr, c->n, c->gsort_scratch, c->grec, c->chunk_table, (uint32_t)gs_emit_chunks(std::max(c->capacity, c->row_cap)),
                         &c->ctl->num_visible, &c->ctl->num_slots, st);
         mark(c, 2);
-        gs_launch_rows(c->arena, c->slot_src, c->rows_sorted, c->ctl, c->rows_status, (uint32_t)c->row_cap, c->M3, c->tileoff, c->rowtot, f, c->valsA,
+        gs_launch_rows(c->arena, c->grec, c->chunk_table, c->rows_sorted, c->ctl, c->rows_status, (uint32_t)c->row_cap, c->M3, c->tileoff, c->rowtot, f, c->valsA,
                        c->ranges, c->grid_persist / 4u, c->sticky, st, mark_cb, c);
         c->keysS = nullptr;
         c->valsS = c->valsA;
@@ -469,10 +467,10 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
         // gaussian index).  Sorting the N_vis visible GAUSSIANS by bucket first (stable, 10 bits, ~16x fewer elements
         // than instances: k_gsort.hip) and emitting their instances in that order leaves only the tile id for the stable
         // instance sort: 2 digits of key/1000 instead of 3 of the key.  The sorted (key,value) arrays are identical.
-        gs_launch_gsort(c->counts, nullptr, c->n, c->gsort_scratch, c->perm, c->scounts, c->offsets, c->chunk_table,
-                        (uint32_t)gs_emit_chunks(c->capacity), nullptr, 0u, &c->ctl->num_visible, &c->ctl->num_intersections, st);
+        gs_launch_gsort(c->counts, nullptr, c->n, c->gsort_scratch, c->grec, c->chunk_table, (uint32_t)gs_emit_chunks(std::max(c->capacity, c->row_cap)),
+                        &c->ctl->num_visible, &c->ctl->num_intersections, st);
         mark(c, 2);
-        gs_launch_emit_balanced(c->gdata, c->scounts, c->offsets, c->perm, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
+        gs_launch_emit_balanced(c->gdata, c->grec, c->chunk_table, f, c->keysA, c->valsA, c->ctl, c->grid_persist * 2,
                                 c->tile_bits, c->tile_passes, c->tile16, st);
         keys16 = c->tile16;
     }
@@ -688,7 +686,7 @@ static int32_t add_shadow(gs_ctx* c) {
     rc = gs_share_splats(s, c);
     if (rc != GS_OK) { gs_destroy(s); return rc; }
     s->emit_order = c->emit_order; s->tile_cull = c->tile_cull; s->debug_view = c->debug_view;
-    s->blend_ablation = c->blend_ablation; s->grid_persist = c->grid_persist; s->timed_from = 0;
+    s->blend_ablation = c->blend_ablation; s->grid_persist = c->grid_persist; s->timed_from = 0; s->tight_nb = c->tight_nb;
     s->use_graph = c->use_graph;
     c->shadows.push_back(s);
     return GS_OK;
@@ -959,6 +957,7 @@ static int32_t set_option_one(gs_ctx* c, int32_t key, int64_t value) {
     case GS_OPT_UNFUSED: return GS_OK; // (removed in ABI 3: the fused projection+scan+emission launch measured slower; accepted, ignored)
     case GS_OPT_DEBUG_VIEW: if (value < 0 || value > 4) break; c->debug_view = (uint32_t)value; return GS_OK;
     case GS_OPT_TILE_CULL: c->tile_cull = (value != 0); return GS_OK;
+    case GS_OPT_PROJ_CHUNKS: if (value != 0 && value != 2 && value != 4 && value != 8) break; c->tight_nb = (uint32_t)value; return GS_OK;
     default: break;
     }
     return fail(GS_ERR_INVALID_ARGUMENT, "gs_set_option: bad key/value %d/%lld", key, (long long)value);

@@ -252,8 +252,7 @@ __global__ __launch_bounds__(256) void gs_emit_kernel(const uint4* __restrict__ 
 // consecutive OUTPUT slots instead; chunk_table (written by the scan) names the gaussian that covers the
 // chunk's first slot, and the wave walks forward from it 64 gaussians at a time.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ counts,
-                                                                const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __restrict__ gdata, const uint4* __restrict__ grec,
                                                                 const uint32_t* __restrict__ chunk_table, GsFrame f,
                                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ values,
                                                                 GsControl* ctl, uint32_t hist_bits, uint32_t hist_passes, uint32_t keys16) {
@@ -281,10 +280,11 @@ __global__ __launch_bounds__(256) void gs_emit_balanced_kernel(const uint4* __re
             const uint32_t k = kbase + lane;
             uint32_t off = 0xFFFFFFFFu, row = 0, yb = 0, gid = 0, cnt = 0;
             if (k < nvis) {
-                gid = perm[k];
-                const uint32_t packed = counts[k]; // sorted order, like offsets and perm
+                const uint4 gr = grec[k]; // {gaussian id, count word, first output slot, -} in (bucket, index) order (k_gsort.hip)
+                gid = gr.x;
+                const uint32_t packed = gr.y;
                 cnt = packed & GS_COUNT_MASK;
-                off = offsets[k];
+                off = gr.z;
                 const uint4 rect = gdata[(uint64_t)gid * 4 + 3];
                 uint32_t xa, wmain, alias;
                 slab_cols_emit(rect.x, rect.z, f, xa, wmain, alias);
@@ -475,10 +475,9 @@ void gs_launch_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, unsig
     hipLaunchKernelGGL(gs_scan_kernel, dim3(blocks), dim3(SCAN_THREADS), 0, st, counts, n, offsets, status, ticket, ctl);
 }
 uint64_t gs_emit_chunks(uint64_t capacity) { return (capacity >> EMIT_CHUNK_SHIFT) + 2; }
-void gs_launch_emit_balanced(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm,
-                             const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, uint32_t grid,
-                             uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st) {
-    hipLaunchKernelGGL(gs_emit_balanced_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, chunk_table, f, keys,
+void gs_launch_emit_balanced(const void* gdata, const void* grec, const uint32_t* chunk_table, const GsFrame& f, uint32_t* keys, uint32_t* values,
+                             GsControl* ctl, uint32_t grid, uint32_t hist_bits, uint32_t hist_passes, bool keys16, hipStream_t st) {
+    hipLaunchKernelGGL(gs_emit_balanced_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)gdata, (const uint4*)grec, chunk_table, f, keys,
                        values, ctl, hist_bits, hist_passes, keys16 ? 1u : 0u);
 }
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,

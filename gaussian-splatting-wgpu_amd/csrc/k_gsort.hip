@@ -12,10 +12,9 @@
 //   hist     every chunk counts the buckets of its visible gaussians      -> M[bucket][chunk] = (gaussians, quantity)
 //   rowscan  every bucket's row of M is scanned over the chunks (exclusive) -> row totals
 //   scatter  every chunk compacts its visible gaussians (index order), ranks them by bucket (wave ballots, stable), reorders
-//            them through LDS, scans their quantity in that order and writes  perm / words / offsets  at
-//            base[bucket] + M[bucket][chunk] + rank; plus, for the reference-binning emission, the chunk table (first
-//            gaussian of every EMIT_CHUNK output slots), or, for the tight row pipeline (k_rows.hip), the arena address of
-//            every row-item slot in depth order.
+//            them through LDS, scans their quantity in that order and writes one record {id, word, prefix, aux} per gaussian
+//            at  base[bucket] + M[bucket][chunk] + rank;  plus the chunk table (first gaussian of every 1024 units of the
+//            quantity) that the reference-binning emission and the row sort of the tight pipeline (k_rows.hip) start from.
 // Position in (bucket, index) order = bucket base + gaussians of that bucket in earlier chunks + rank inside the chunk: the
 // chunks are index ranges, so the order inside a bucket is the index order the reference's stable sort keeps.
 // All three are HBM-trivial (24-50 MB); what they cost is their launches.
@@ -26,6 +25,9 @@
 #define GC (GC_THREADS * GC_ITEMS) // gaussian indices per chunk
 #define GBINS 1024                 // bucket = u32(min(50 depth, 999)) < 1000 (write_tile_ids.wgsl:31)
 #define GS_EMIT_CHUNK_SHIFT 10     // = EMIT_CHUNK_SHIFT of k_binning.hip
+// The (bucket, chunk) table is stored [bucket / 8][chunk][bucket % 8]: the 1024 entries a chunk's workgroup writes (hist) or
+// reads (scatter) are 128 whole 64-byte sectors instead of 1024 partial ones, and a bucket's row is still a strided stream.
+__device__ __forceinline__ uint64_t m_index(uint32_t b, uint32_t chunk, uint32_t NT) { return ((uint64_t)(b >> 3) * NT + chunk) * 8u + (b & 7u); }
 
 __device__ __forceinline__ uint32_t sat32(unsigned long long v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; }
 
@@ -48,7 +50,11 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_hist_kernel(const uint32_
         }
     }
     __syncthreads();
-    for (uint32_t b = tid; b < GBINS; b += GC_THREADS) M[(uint64_t)b * NT + chunk] = make_uint2(s_cnt[b], sat32(s_sum[b]));
+#pragma unroll
+    for (uint32_t i = 0; i < GBINS / GC_THREADS; ++i) { // thread t: buckets 4t .. 4t+3 (32 contiguous bytes)
+        const uint32_t b = tid * (GBINS / GC_THREADS) + i;
+        M[m_index(b, chunk, NT)] = make_uint2(s_cnt[b], sat32(s_sum[b]));
+    }
 }
 
 // exclusive scan of (count, quantity) over a workgroup: each thread holds the sum of its consecutive elements in v; the
@@ -81,23 +87,46 @@ __device__ __forceinline__ GsPair block_excl2(GsPair v, uint32_t tid, GsPair* s_
     return r;
 }
 
+// One workgroup per 8 buckets (one 64-byte sector per chunk): thread (cl = t / 8, sub = t % 8) owns the chunks
+// [cl * per, (cl + 1) * per) of bucket 8 * blockIdx + sub; the 32 partial sums of a bucket are combined through LDS.
 __global__ __launch_bounds__(GC_THREADS) void gs_gsort_rowscan_kernel(uint2* __restrict__ M, uint32_t NT, uint32_t n, uint2* __restrict__ rowtot) {
-    __shared__ GsPair s_w[GC_THREADS / 64];
-    const uint32_t nt = (n + GC - 1) / GC, b = blockIdx.x, tid = threadIdx.x;
-    uint2* row = M + (uint64_t)b * NT;
-    const uint32_t per = (nt + GC_THREADS - 1) / GC_THREADS; // consecutive chunks per thread
-    GsPair acc; acc.x = 0u; acc.y = 0ull;
-    for (uint32_t i = 0; i < per; ++i) {
-        const uint32_t t = tid * per + i;
-        if (t < nt) { const uint2 v = row[t]; acc.x += v.x; acc.y += v.y; }
+    __shared__ uint32_t s_x[32][8];
+    __shared__ unsigned long long s_y[32][8];
+    const uint32_t nt = (n + GC - 1) / GC, tid = threadIdx.x, cl = tid >> 3, sub = tid & 7u;
+    const uint32_t per = (nt + 31u) / 32u;
+    const uint32_t c0 = cl * per < nt ? cl * per : nt, c1 = (cl + 1u) * per < nt ? (cl + 1u) * per : nt;
+    uint2* row = M + (uint64_t)blockIdx.x * NT * 8u + sub;
+    uint32_t ax = 0;
+    unsigned long long ay = 0;
+    for (uint32_t c = c0; c < c1; c += 8u) {
+        uint2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (c + k < c1) ? row[(uint64_t)(c + k) * 8u] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ax += v[k].x; ay += v[k].y; }
     }
-    GsPair total;
-    GsPair run = block_excl2(acc, tid, s_w, total);
-    for (uint32_t i = 0; i < per; ++i) {
-        const uint32_t t = tid * per + i;
-        if (t < nt) { const uint2 v = row[t]; row[t] = make_uint2(run.x, sat32(run.y)); run.x += v.x; run.y += v.y; }
+    s_x[cl][sub] = ax; s_y[cl][sub] = ay;
+    __syncthreads();
+    uint32_t rx = 0, tx = 0;
+    unsigned long long ry = 0, ty = 0;
+#pragma unroll 8
+    for (uint32_t k = 0; k < 32u; ++k) {
+        const uint32_t vx = s_x[k][sub];
+        const unsigned long long vy = s_y[k][sub];
+        if (k < cl) { rx += vx; ry += vy; }
+        tx += vx; ty += vy;
     }
-    if (tid == 0) rowtot[b] = make_uint2(total.x, sat32(total.y));
+    for (uint32_t c = c0; c < c1; c += 8u) {
+        uint2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (c + k < c1) ? row[(uint64_t)(c + k) * 8u] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (c + k < c1) row[(uint64_t)(c + k) * 8u] = make_uint2(rx, sat32(ry));
+            rx += v[k].x; ry += v[k].y;
+        }
+    }
+    if (cl == 0) rowtot[blockIdx.x * 8u + sub] = make_uint2(tx, sat32(ty));
 }
 
 struct GsortShared {
@@ -110,15 +139,16 @@ struct GsortShared {
 };
 static_assert(GC / GBINS == GC_THREADS / 64, "one ranking row per wave");
 
-// aux_in (optional, tight row pipeline): a second per-gaussian word (the arena address of its row-item slots) carried along;
-// slot_src (with it): slot_src[offsets[g] + i] = aux + i for every slot i of gaussian g, i.e. where in the arena the i-th
-// row-item slot of the depth-ordered slot sequence lives.  totals: [0] visible gaussians, [1] total quantity (saturated).
+// Output: ONE 16-byte record per visible gaussian in (bucket, index) order -- {gaussian id, count word, exclusive prefix of the
+// quantity, aux} -- because a (chunk, bucket) run is about two gaussians long: four separate arrays were four scattered 4-byte
+// stores each (round 2), a record is one 16-byte store.  aux_in (optional, tight row pipeline): a second per-gaussian word
+// (the arena address of its row-item slots).  chunk_table[c] = the gaussian whose quantity interval holds c * 1024 (the
+// reference-binning emission and the row sort start there).  tot_*: visible gaussians, total quantity (saturated).
 __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint32_t* __restrict__ words, const uint32_t* __restrict__ aux_in, uint32_t n,
                                                                       const uint2* __restrict__ M, uint32_t NT, const uint2* __restrict__ rowtot,
-                                                                      uint32_t* __restrict__ perm, uint32_t* __restrict__ scounts,
-                                                                      uint32_t* __restrict__ offsets, uint32_t* __restrict__ chunk_table,
-                                                                      uint32_t chunk_cap, uint32_t* __restrict__ slot_src, uint32_t slot_cap,
-                                                                      uint32_t* __restrict__ tot_visible, uint32_t* __restrict__ tot_quantity) {
+                                                                      uint4* __restrict__ grec, uint32_t* __restrict__ chunk_table,
+                                                                      uint32_t chunk_cap, uint32_t* __restrict__ tot_visible,
+                                                                      uint32_t* __restrict__ tot_quantity) {
     __shared__ GsortShared S;
     const uint32_t chunk = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -136,7 +166,7 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
 #pragma unroll
         for (uint32_t i = 0; i < BPT; ++i) {
             const uint32_t b = tid * BPT + i;
-            const uint2 m = M[(uint64_t)b * NT + chunk];
+            const uint2 m = M[m_index(b, chunk, NT)];
             S.base[b] = make_uint2(run.x + m.x, sat32(run.y + m.y));
             run.x += t[i].x; run.y += t[i].y;
         }
@@ -280,18 +310,12 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
         const uint32_t g = base.x + (pos - first);
         const unsigned long long off64 = (unsigned long long)base.y + (P[pos] - P[first]);
         const uint32_t off = sat32(off64);
-        perm[g] = S.id[pos];
-        scounts[g] = x;
-        offsets[g] = off;
+        grec[g] = make_uint4(S.id[pos], x, off, S.aux[pos]);
         const uint32_t cnt = x & GS_COUNT_MASK; // > 0: only visible gaussians are here
-        if (chunk_table && off != 0xFFFFFFFFu) {
+        if (off != 0xFFFFFFFFu) {
             const unsigned long long lastq = (off64 + cnt - 1ull) >> GS_EMIT_CHUNK_SHIFT;
             const uint32_t last = lastq > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lastq;
             for (uint32_t c = (uint32_t)((off64 + (1u << GS_EMIT_CHUNK_SHIFT) - 1ull) >> GS_EMIT_CHUNK_SHIFT); c <= last && c < chunk_cap; ++c) chunk_table[c] = g;
-        }
-        if (slot_src) {
-            const uint32_t a = S.aux[pos];
-            for (uint32_t i = 0; i < cnt && off64 + i < (unsigned long long)slot_cap; ++i) slot_src[off + i] = a + i;
         }
     }
 }
@@ -300,16 +324,15 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
 uint32_t gs_gsort_tiles(uint32_t n) { return (n + GC - 1) / GC; }
 uint64_t gs_gsort_scratch_bytes(uint32_t n) { return ((uint64_t)GBINS * gs_gsort_tiles(n ? n : 1) + GBINS) * sizeof(uint2); }
 // words: one word per gaussian INDEX (quantity in the low 22 bits, depth bucket in the high 10; 0 = not visible); scratch:
-// gs_gsort_scratch_bytes(n) bytes.  Outputs in (bucket, index) order; tot_visible / tot_quantity: device words.
-void gs_launch_gsort(const uint32_t* words, const uint32_t* aux_in, uint32_t n, void* scratch, uint32_t* perm, uint32_t* scounts, uint32_t* offsets,
-                     uint32_t* chunk_table, uint32_t chunk_cap, uint32_t* slot_src, uint32_t slot_cap, uint32_t* tot_visible,
-                     uint32_t* tot_quantity, hipStream_t st) {
+// gs_gsort_scratch_bytes(n) bytes.  Output records in (bucket, index) order; tot_visible / tot_quantity: device words.
+void gs_launch_gsort(const uint32_t* words, const uint32_t* aux_in, uint32_t n, void* scratch, void* grec, uint32_t* chunk_table, uint32_t chunk_cap,
+                     uint32_t* tot_visible, uint32_t* tot_quantity, hipStream_t st) {
     if (!n) return;
     const uint32_t NT = gs_gsort_tiles(n);
     uint2* M = (uint2*)scratch;
     uint2* rowtot = M + (uint64_t)GBINS * NT;
     hipLaunchKernelGGL(gs_gsort_hist_kernel, dim3(NT), dim3(GC_THREADS), 0, st, words, n, M, NT);
-    hipLaunchKernelGGL(gs_gsort_rowscan_kernel, dim3(GBINS), dim3(GC_THREADS), 0, st, M, NT, n, rowtot);
-    hipLaunchKernelGGL(gs_gsort_scatter_kernel, dim3(NT), dim3(GC_THREADS), 0, st, words, aux_in, n, (const uint2*)M, NT, (const uint2*)rowtot, perm,
-                       scounts, offsets, chunk_table, chunk_cap, slot_src, slot_cap, tot_visible, tot_quantity);
+    hipLaunchKernelGGL(gs_gsort_rowscan_kernel, dim3(GBINS / 8), dim3(GC_THREADS), 0, st, M, NT, n, rowtot);
+    hipLaunchKernelGGL(gs_gsort_scatter_kernel, dim3(NT), dim3(GC_THREADS), 0, st, words, aux_in, n, (const uint2*)M, NT, (const uint2*)rowtot,
+                       (uint4*)grec, chunk_table, chunk_cap, tot_visible, tot_quantity);
 }

@@ -202,19 +202,20 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         // indexed by the gaussian
         if (tid == 0) s_misc[1] = 0u;
         __syncthreads();
+        constexpr int GRP = 2 * NB < 8 ? 2 * NB : 8; // positions a thread keeps in flight
 #pragma unroll 1
-        for (int h = 0; h < NB / 4; ++h) {
-            float X[8], Y[8], Z[8], S[8];
+        for (int h = 0; h < 2 * NB / GRP; ++h) {
+            float X[GRP], Y[GRP], Z[GRP], S[GRP];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t i = base + (uint32_t)(h * 8 + k) * 256u + tid;
+            for (int k = 0; k < GRP; ++k) {
+                const uint32_t i = base + (uint32_t)(h * GRP + k) * 256u + tid;
                 const bool in = i < f.n;
                 X[k] = in ? s.px[i] : 0.0f; Y[k] = in ? s.py[i] : 0.0f; Z[k] = in ? s.pz[i] : 0.0f;
                 S[k] = (in && !f.full) ? s.smax[i] : 0.0f;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t off = (uint32_t)(h * 8 + k) * 256u + tid;
+            for (int k = 0; k < GRP; ++k) {
+                const uint32_t off = (uint32_t)(h * GRP + k) * 256u + tid;
                 const uint32_t i = base + off;
                 bool v = false;
                 if (i < f.n) {
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
     if (TIGHT) { // the workgroup's items per tile row -> the row sort's digit histogram
         __syncthreads();
         const uint32_t c = s_rowhist[tid];
-        if (c) atomicAdd(&to.ctl->rowhist[tid], c);
+        if (c) atomicAdd(&to.ctl->rowhist[bid & 7u][tid], c);
     }
 }
 
@@ -451,12 +452,16 @@ void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream
 // The projection's launch as data: the one kernel of a frame whose arguments change from frame to frame (the uniforms, by
 // value), so a captured frame graph (gs_runtime.hip) re-launches it with updated parameters.
 void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
-                           bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl) {
-    // cull chunks per workgroup (see NB): tight path 8; else 8 for a slab narrower than 30 % of the canvas, 4 up to 75 %, else 1
+                           bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl, uint32_t tight_nb) {
+    // cull chunks per workgroup (see NB).  Reference binning: 8 for a slab narrower than 30 % of the canvas, 4 up to 75 %, else 1.
+    // Tight: 2 on the whole canvas (5 958 workgroups at 6.1 M gaussians: with 8 the 1 490 workgroups were 1.45 residency rounds,
+    // the second one half empty), 8 / 4 for slabs as above.
     const uint32_t wcols = f.col1 - f.col0;
-    const uint32_t nb = tight ? 8u : (f.full || wcols * 4u > f.ntx * 3u ? 1u : (wcols * 10u > f.ntx * 3u ? 4u : 8u));
+    uint32_t nb = f.full || wcols * 4u > f.ntx * 3u ? 1u : (wcols * 10u > f.ntx * 3u ? 4u : 8u);
+    if (tight) nb = tight_nb ? tight_nb : (nb == 1u ? 2u : nb);
     L.blocks = (f.n + PRE_G * nb - 1) / (PRE_G * nb);
-    if (tight) L.func = (const void*)&gs_preprocess_kernel<true, 8>;
+    if (tight) L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<true, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<true, 4>
+                                                                                       : (const void*)&gs_preprocess_kernel<true, 2>;
     else L.func = nb == 8u ? (const void*)&gs_preprocess_kernel<false, 8> : nb == 4u ? (const void*)&gs_preprocess_kernel<false, 4>
                                                                                         : (const void*)&gs_preprocess_kernel<false, 1>;
     L.s = s; L.u = u; L.f = f; L.gdata = gdata; L.counts = counts;

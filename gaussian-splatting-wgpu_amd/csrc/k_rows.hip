@@ -10,10 +10,10 @@
 // for the ranges: 4 launches, 364 us at config B.  The observation behind this file: a gaussian's instances are, per tile row,
 // ONE run of consecutive tiles, so the unit that has to be ordered by tile ROW is the row item (7 M, not 18.4 M), and inside
 // one tile row the column is a digit of at most 8 bits.  Hence (MSD first):
-//   gs_rows_sort_kernel    the row items, gathered in depth order (slot_src, written by the gaussian-level sort), are
+//   gs_rows_sort_kernel    the row items, gathered in depth order (through the gaussian-level sort's records), are
 //                          partitioned STABLY by tile row: one Onesweep-style pass (ticketed tiles, 4-byte look-back granules),
 //                          digit histogram = GsControl::rowhist, which the projection accumulated.
-//   gs_rows_count_kernel   chunks of 1024 consecutive items of ONE tile row count their instances per tile column (difference
+//   gs_rows_count_kernel   chunks of 512 consecutive items of ONE tile row count their instances per tile column (difference
 //                          array + scan) -> M3[chunk][column].
 //   gs_rows_scan_kernel    per tile row: prefix of M3 over the row's chunks (so no chunk ever waits for another), tile totals,
 //                          their prefix inside the row, the row's total.
@@ -23,7 +23,7 @@
 //                          is ever materialised, and `ranges` falls out of the scan.
 // Order inside a tile = item order inside the tile row = depth order of the gaussians = (bucket, index): the reference's.
 // Every kernel is integer work on 12-byte items and 4-byte values; algorithmic bytes per frame (R items, I instances):
-// 12 R (+4 R slot addresses) read + 12 R written by the row sort, 12 R read twice by count / expand, 4 I written.
+// 12 R read + 12 R written by the row sort, 12 R read twice by count / expand, 4 I written.
 #include "gs_device.h"
 #include "gs_tight.h"
 
@@ -38,8 +38,11 @@ typedef uint32_t gs_item3 __attribute__((ext_vector_type(3), aligned(4)));
 #define RA_FLAGS (3u << 30)
 #define RA_VALUE (~RA_FLAGS)
 
-#define RB_CH 1024u  // items per chunk
-#define RB_SB 4096u  // instances per sub-batch of the expansion (256 threads x 16)
+#define RB_CH 512u   // items per chunk
+#define RB_IT (RB_CH / 256u)
+#define RB_SB 2048u  // instances per sub-batch of the expansion (256 threads x 8): 25 KB of LDS, six workgroups per CU
+#define RB_PER (RB_SB / 256u)
+#define RB_WSL (RB_SB / 4u) // slots of one wave
 
 // ------------------------------------------------------------------------------------------------
 // Row sort: stable partition of the row items by tile row.
@@ -51,20 +54,31 @@ struct RowSortShared {
     uint32_t dbase[256];          // exclusive scan of GsControl::rowhist
     uint32_t wsum[RA_WAVES];
     uint32_t tile, nvalid;
-    uint32_t it[RA_TILE * 3];
+    union {
+        uint32_t it[RA_TILE * 3];                 // the reorder buffer
+        struct {                                  // before it: the gaussians whose slots the tile holds (first slot, arena address)
+            uint32_t goff[RA_TILE + 8], gptr[RA_TILE + 8];
+            unsigned short mark[RA_TILE];         // mark[s] = k + 1: gaussian k's first slot is tile slot s
+        } g;
+    } u;
 };
 
-__global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t* __restrict__ arena, const uint32_t* __restrict__ slot_src,
-                                                                  uint32_t* __restrict__ rows_out, GsControl* ctl, uint32_t* __restrict__ status,
-                                                                  uint32_t row_cap) {
+// grec / chunk_table: the gaussian-level sort's records {id, slots | bucket << 22, first slot, arena address} in depth order and
+// the gaussian holding every 1024th slot (k_gsort.hip).  Slot s of the depth-ordered slot sequence belongs to the gaussian k
+// with first_slot[k] <= s < first_slot[k + 1] and lives at arena[address[k] + s - first_slot[k]]: every gaussian of the tile
+// marks its first slot in LDS and a running maximum (DPP) hands every slot its owner.
+__global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t* __restrict__ arena, const uint4* __restrict__ grec,
+                                                                  const uint32_t* __restrict__ chunk_table, uint32_t* __restrict__ rows_out,
+                                                                  GsControl* ctl, uint32_t* __restrict__ status, uint32_t row_cap) {
     __shared__ RowSortShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t n = ctl->num_slots;
     if (n > row_cap) n = row_cap;
     const uint32_t ntiles = (n + RA_TILE - 1) / RA_TILE;
+    const uint32_t nvis = ctl->num_visible;
     {   // first slot of every tile row's run: exclusive scan of the digit histogram (every workgroup for itself)
-        const uint32_t c = ctl->rowhist[tid];
+        const uint32_t c = gs_rowhist(ctl, tid);
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) sh.wsum[w] = incl;
         __syncthreads();
@@ -78,15 +92,44 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
         __syncthreads();
         const uint32_t tile = sh.tile;
         if (tile >= ntiles) break; // uniform
-        const uint32_t wbase = tile * RA_TILE + w * (64 * RA_ITEMS) + lane;
+        const uint32_t s0 = tile * RA_TILE, s_end = (s0 + RA_TILE < n) ? s0 + RA_TILE : n;
+        // the gaussians g0 .. g1 hold the tile's slots (g1 holds the first slot of the next tile, or is the last one)
+        const uint32_t g0 = chunk_table[s0 >> 10];
+        const uint32_t g1 = (s_end < n) ? chunk_table[s_end >> 10] : nvis - 1u;
+        uint32_t K = (g1 >= g0) ? g1 - g0 + 1u : 1u;
+        if (K > RA_TILE + 8u) K = RA_TILE + 8u; // (cannot happen: every gaussian here has at least one slot)
+        for (uint32_t k = tid; k < RA_TILE / 2u; k += RA_THREADS) reinterpret_cast<uint32_t*>(sh.u.g.mark)[k] = 0u;
+        __syncthreads();
+        for (uint32_t k = tid; k < K; k += RA_THREADS) {
+            const uint4 rec = (g0 + k < nvis) ? grec[g0 + k] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+            sh.u.g.goff[k] = rec.z;
+            sh.u.g.gptr[k] = rec.w;
+            if (rec.z >= s0 && rec.z < s_end) sh.u.g.mark[rec.z - s0] = (unsigned short)(k + 1u);
+        }
+        __syncthreads();
+        uint32_t carry;
+        {   // owner of the wave's first slot: the last gaussian whose first slot is <= it
+            const uint32_t x0 = s0 + w * (64 * RA_ITEMS);
+            uint32_t e = 0;
+#pragma unroll
+            for (int step = 2048; step >= 1; step >>= 1) {
+                const uint32_t m = e + step;
+                if (m < K && sh.u.g.goff[m] <= x0) e = m;
+            }
+            carry = e + 1u;
+        }
         uint32_t ix[RA_ITEMS], iy[RA_ITEMS], iz[RA_ITEMS];
         uint32_t rank2[RA_ITEMS / 2];
 #pragma unroll
         for (int j = 0; j < RA_ITEMS; ++j) {
-            const uint32_t slot = wbase + j * 64;
+            const uint32_t sp = w * (64 * RA_ITEMS) + j * 64 + lane, slot = s0 + sp;
+            uint32_t m = wave_incl_max((uint32_t)sh.u.g.mark[sp]);
+            m = m > carry ? m : carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             ix[j] = GS_ROW_HOLE; iy[j] = 0u; iz[j] = 0u;
             if (slot < n) {
-                const uint32_t src = slot_src[slot];
+                const uint32_t k = m - 1u;
+                const uint32_t src = sh.u.g.gptr[k] + (slot - sh.u.g.goff[k]);
                 if (src < row_cap) {
                     const gs_item3 v = *reinterpret_cast<const gs_item3*>(arena + (uint64_t)src * 3u);
                     ix[j] = v.x; iy[j] = v.y; iz[j] = v.z;
@@ -170,9 +213,9 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
             const uint32_t d = ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu);
             const uint32_t r = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
             const uint32_t pos = sh.hist[w][d] + r;
-            sh.it[pos * 3 + 0] = ix[j];
-            sh.it[pos * 3 + 1] = iy[j];
-            sh.it[pos * 3 + 2] = iz[j];
+            sh.u.it[pos * 3 + 0] = ix[j];
+            sh.u.it[pos * 3 + 1] = iy[j];
+            sh.u.it[pos * 3 + 2] = iz[j];
         }
         __syncthreads();
         const uint32_t nvalid = sh.nvalid;
@@ -181,7 +224,7 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
             const uint32_t pos = j * RA_THREADS + tid;
             if (pos < nvalid) {
                 gs_item3 v;
-                v.x = sh.it[pos * 3 + 0]; v.y = sh.it[pos * 3 + 1]; v.z = sh.it[pos * 3 + 2];
+                v.x = sh.u.it[pos * 3 + 0]; v.y = sh.u.it[pos * 3 + 1]; v.z = sh.u.it[pos * 3 + 2];
                 const uint32_t g = sh.gbase[v.y & 0xFFu] + pos;
                 if (g < row_cap) *reinterpret_cast<gs_item3*>(rows_out + (uint64_t)g * 3u) = v;
             }
@@ -202,7 +245,7 @@ struct RowTables {
 // 256 threads; leaves the tables valid after its last barrier
 __device__ __forceinline__ void row_tables(RowTables& T, const GsControl* ctl, uint32_t tid) {
     const uint32_t lane = tid & 63, w = tid >> 6;
-    const uint32_t c = ctl->rowhist[tid], ch = (c + RB_CH - 1u) / RB_CH;
+    const uint32_t c = gs_rowhist(ctl, tid), ch = (c + RB_CH - 1u) / RB_CH;
     const uint32_t ic = wave_incl_scan(c, lane), ih = wave_incl_scan(ch, lane);
     if (lane == 63) { T.w4[w] = ic; T.w4[4 + w] = ih; }
     __syncthreads();
@@ -275,7 +318,7 @@ __global__ __launch_bounds__(1024) void gs_rows_scan_kernel(const GsControl* ctl
     {
         const uint32_t lane = tid & 63, w = tid >> 6;
         uint32_t cc = 0, ch = 0;
-        if (tid < 256u) { cc = ctl->rowhist[tid]; ch = (cc + RB_CH - 1u) / RB_CH; }
+        if (tid < 256u) { cc = gs_rowhist(ctl, tid); ch = (cc + RB_CH - 1u) / RB_CH; }
         const uint32_t ic = wave_incl_scan(cc, lane), ih = wave_incl_scan(ch, lane);
         if (tid < 256u && lane == 63) { T.w4[w] = ic; T.w4[4 + w] = ih; }
         __syncthreads();
@@ -417,11 +460,11 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
         const uint32_t i0 = S.T.ibase[r] + (c - S.T.cbase[r]) * RB_CH;
         const uint32_t i1 = (i0 + RB_CH < S.T.ibase[r + 1]) ? i0 + RB_CH : S.T.ibase[r + 1];
         const uint32_t ni = i1 - i0;
-        // ---- the chunk's items (thread t: items 4t .. 4t+3, consecutive) and the prefix of their lengths ----
-        uint32_t len[4], lsum = 0;
+        // ---- the chunk's items (thread t: RB_IT consecutive ones) and the prefix of their lengths ----
+        uint32_t len[RB_IT], lsum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e = tid * 4u + k;
+        for (int k = 0; k < (int)RB_IT; ++k) {
+            const uint32_t e = tid * RB_IT + k;
             len[k] = 0u;
             if (e < ni) {
                 const gs_item3 v = *reinterpret_cast<const gs_item3*>(rows + (uint64_t)(i0 + e) * 3u);
@@ -439,7 +482,7 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             for (int k = 0; k < 4; ++k) { if (k < (int)w) b += S.wsum[k]; all += S.wsum[k]; }
             uint32_t run = b + incl - lsum;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { S.x.e.P[tid * 4u + k] = run; run += len[k]; }
+            for (int k = 0; k < (int)RB_IT; ++k) { S.x.e.P[tid * RB_IT + k] = run; run += len[k]; }
             if (tid == 0) { S.x.e.P[RB_CH] = all; S.total = all; }
         }
         // first list slot of column `tid` for this chunk: tile start + what the row's earlier chunks put there
@@ -451,9 +494,9 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             // ---- owner marks: an item whose first instance falls into the sub-batch marks that slot ----
             if (s0) {
                 __syncthreads(); // the previous sub-batch's stores have read x.vals: P / mark are rebuilt (P from the items kept in LDS)
-                uint32_t l2[4], ls = 0;
+                uint32_t l2[RB_IT], ls = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const uint32_t e = tid * 4u + k; l2[k] = e < ni ? ((S.w1[e] >> 16) & 0xFFu) + 1u : 0u; ls += l2[k]; }
+                for (int k = 0; k < (int)RB_IT; ++k) { const uint32_t e = tid * RB_IT + k; l2[k] = e < ni ? ((S.w1[e] >> 16) & 0xFFu) + 1u : 0u; ls += l2[k]; }
                 const uint32_t incl = wave_incl_scan(ls, lane);
                 if (lane == 63) S.wsum[w] = incl;
                 __syncthreads();
@@ -462,39 +505,41 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
                 for (int k = 0; k < 4; ++k) if (k < (int)w) b += S.wsum[k];
                 uint32_t run = b + incl - ls;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { S.x.e.P[tid * 4u + k] = run; run += l2[k]; }
+                for (int k = 0; k < (int)RB_IT; ++k) { S.x.e.P[tid * RB_IT + k] = run; run += l2[k]; }
                 if (tid == 0) S.x.e.P[RB_CH] = ninst;
             }
             for (uint32_t k = tid; k < RB_SB / 2u; k += 256u) reinterpret_cast<uint32_t*>(S.x.e.mark)[k] = 0u;
             for (uint32_t k = lane; k < 256; k += 64) S.hist[w][k] = 0u;
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t e = tid * 4u + k;
+            for (int k = 0; k < (int)RB_IT; ++k) {
+                const uint32_t e = tid * RB_IT + k;
                 if (e < ni) {
                     const uint32_t p0 = S.x.e.P[e];
                     if (p0 >= s0 && p0 < s0 + RB_SB) S.x.e.mark[p0 - s0] = (unsigned short)(e + 1u);
                 }
             }
             __syncthreads();
-            // ---- expansion: thread slot (w, j, lane) = instance s0 + w*1024 + j*64 + lane ----
+            // ---- expansion: thread slot (w, j, lane) = instance s0 + w * RB_WSL + j * 64 + lane ----
             // owner of the wave's first slot: the last item whose prefix is <= it
             uint32_t carry;
             {
-                const uint32_t x0 = s0 + w * 1024u;
+                const uint32_t x0 = s0 + w * RB_WSL;
                 uint32_t e = 0;
 #pragma unroll
-                for (int step = 512; step >= 1; step >>= 1) {
+                for (int step = (int)(RB_CH / 2u); step >= 1; step >>= 1) {
                     const uint32_t m = e + step;
                     if (m < ni && S.x.e.P[m] <= x0) e = m;
                 }
                 carry = e + 1u;
             }
-            uint32_t val[16], col4[4] = {0u, 0u, 0u, 0u};
-            uint32_t rank2[8];
+            uint32_t val[RB_PER], col4[RB_PER / 4u];
+            uint32_t rank2[RB_PER / 2u];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t sp = w * 1024u + j * 64u + lane, x = s0 + sp;
+            for (int j = 0; j < (int)(RB_PER / 4u); ++j) col4[j] = 0u;
+#pragma unroll
+            for (int j = 0; j < (int)RB_PER; ++j) {
+                const uint32_t sp = w * RB_WSL + j * 64u + lane, x = s0 + sp;
                 uint32_t m = wave_incl_max((uint32_t)S.x.e.mark[sp]);
                 m = m > carry ? m : carry;
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
@@ -510,7 +555,7 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             }
             // ---- rank by column inside the wave (slots past the end take digit 255: no tile column has it, ntx <= 255) ----
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < (int)RB_PER; ++j) {
                 const uint32_t d = (col4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
 #pragma unroll
@@ -552,7 +597,7 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < (int)RB_PER; ++j) {
                 const uint32_t d = (col4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 const uint32_t rr = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
                 const uint32_t pos = S.hist[w][d] + rr;
@@ -562,7 +607,7 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             __syncthreads();
             const uint32_t nvalid = S.nvalid;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < (int)RB_PER; ++j) {
                 const uint32_t pos = j * 256u + tid;
                 if (pos < nvalid) {
                     const uint32_t dst = S.gbase[S.cols[pos]] + pos;
@@ -593,17 +638,18 @@ __global__ __launch_bounds__(256) void gs_rows_rebuild_keys_kernel(const uint32_
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_rows_sort_tiles(uint64_t row_cap) { return (uint32_t)((row_cap + RA_TILE - 1) / RA_TILE); }
 uint32_t gs_rows_chunks(uint64_t row_cap) { return (uint32_t)(row_cap / RB_CH + 256u); }
-// cus: compute units (grids are sized by residency: three workgroups of the sort / the expansion fit a CU, eight of the count)
-void gs_launch_rows(const uint32_t* arena, const uint32_t* slot_src, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
+// cus: compute units (grids are sized by residency: three workgroups of the sort, six of the expansion, eight of the count fit a CU)
+void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chunk_table, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
                     uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
                     uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg) {
     const uint32_t chunk_cap = gs_rows_chunks(row_cap);
     if (!cus) cus = 1;
-    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, slot_src, rows_sorted, ctl, sort_status, row_cap);
+    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
+                       row_cap);
     if (mark) mark(mark_arg, 3);
     hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * 8u), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
     hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap);
-    hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * 3u), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
+    hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * 6u), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
                        (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, sticky);
 }
 void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,

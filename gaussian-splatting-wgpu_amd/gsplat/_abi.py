@@ -29,6 +29,7 @@ GS_OPT_DEBUG_VIEW = 6
 GS_OPT_TILE_CULL = 7
 GS_OPT_FRAMES_IN_FLIGHT = 8
 GS_OPT_FRAME_GRAPH = 9
+GS_OPT_PROJ_CHUNKS = 10
 
 # every symbol include/gsplat/gs_abi.h declares
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",

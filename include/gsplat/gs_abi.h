@@ -218,6 +218,7 @@ int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
                                     events (GS_FLAG_TIMING), gs_render_debug and the profiler taps are issued directly as before;
                                     the capture is redone when a buffer moves (capacity growth), an option or the emission order
                                     changes.  Renderer.animate re-encodes every pass every frame (renderer.ts:394-587).  Default 0. */
+#define GS_OPT_PROJ_CHUNKS 10     /* tuning: 512-gaussian cull chunks per workgroup of the tight projection (2, 4 or 8; 0 = automatic)  */
 int32_t gs_set_option(gs_ctx* ctx, int32_t key, int64_t value);
 /* Width in pixels of this ctx's slab (= width when the ctx owns the whole screen). */
 int32_t gs_slab_width(gs_ctx* ctx, uint32_t* px_begin, uint32_t* px_width);

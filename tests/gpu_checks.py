@@ -48,6 +48,7 @@ def check_image(r, ref, exact_image, max_ill=0.005, report=None):
         report.update({"flagged_fraction": float(ill.mean()), "max_err_unflagged": float(err[~ill].max(initial=0.0)),
                        "max_err_flagged": float(err[ill].max(initial=0.0)),
                        "fraction_over_1e-4": float((err > 1e-4).mean()), "fraction_over_1e-3": float((err > 1e-3).mean()),
+                       "pixels_over_1e-4": int((err > 1e-4).sum()), "max_err": float(err.max(initial=0.0)), "pixels": int(err.size),
                        "err_p50": float(np.percentile(err, 50)), "err_p99": float(np.percentile(err, 99)),
                        "rgba8_fraction_differing": float((d8 > 0).mean()), "rgba8_fraction_over_1_lsb": float((d8 > 1).mean()),
                        "rgba8_max_lsb": int(d8.max(initial=0))})
