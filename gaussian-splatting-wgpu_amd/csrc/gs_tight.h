@@ -35,6 +35,7 @@ struct TightG {
     float rcx;         // 1 / cx
     float xmax, ymax;  // half extents of E in x and y, inflated
     float dyR, eR;     // dy of E's rightmost point (the leftmost is at -dyR) and the uncertainty of that estimate
+    float kc, qa, qb;  // chord at offset dy: centre kc dy, half width sqrt(qa dy^2 + qb) / cx  (tight_chord)
     uint32_t mode;     // 0: cannot pass anywhere (opacity < 1/255), 1: ellipse test, 2: keep the reference's whole rect
 };
 
@@ -54,6 +55,11 @@ __device__ __forceinline__ TightG tight_setup(float uvx, float uvy, float cx, fl
     g.lim2 = 2.0f * lim;
     g.rcx = 1.0f / cx;
     g.xmax = 0.0f; g.ymax = 0.0f; g.dyR = 0.0f; g.eR = 0.0f;
+    // the chord's discriminant (cy dy)^2 - cx cz dy^2 + lim2 cx, inflated by 1e-5 of the magnitude of its terms (the rounding of
+    // the products and of the difference is ~1e-7 of it), as a polynomial in dy^2: two instructions per chord instead of nine
+    g.kc = -(cy * g.rcx);
+    g.qa = (cyy - g.cxz) + 1.0e-5f * (cyy + g.cxz);
+    g.qb = (g.lim2 * cx) * 1.00001f;
     const bool pd = (cx > 0.0f) && (cz > 0.0f) && (D > 0.0f);
     const bool fin = tight_finite(g.gx) && tight_finite(g.gy) && tight_finite(cx) && tight_finite(cy) && tight_finite(cz) && tight_finite(g.rcx);
     if (lim < 0.0f) { g.mode = 0u; return g; }                                  // (-inf included; NaN falls through to mode 2)
@@ -73,12 +79,10 @@ __device__ __forceinline__ TightG tight_setup(float uvx, float uvy, float cx, fl
 // Chord of E at vertical offset dy: [xlo, xhi] in dx; false if the line misses E.  The discriminant is inflated by its own
 // rounding bound, so a chord is never missed or shortened by cancellation (cy^2 dy^2 against cx cz dy^2).
 __device__ __forceinline__ bool tight_chord(const TightG& g, float dy, float& xlo, float& xhi) {
-    const float t = g.cy * dy;
-    const float p1 = t * t, p2 = g.cxz * (dy * dy), p3 = g.lim2 * g.cx;
-    const float up = ((p1 - p2) + p3) + 1.0e-5f * ((p1 + p2) + p3);
+    const float up = __builtin_fmaf(dy * dy, g.qa, g.qb);
     if (!(up >= 0.0f)) return false;
     const float hw = __builtin_amdgcn_sqrtf(up) * g.rcx; // v_sqrt_f32 (1 ulp): `up` is inflated by 1e-5 of its terms, the strip adds 0.02 px of slack
-    const float c = -(t * g.rcx);
+    const float c = g.kc * dy;
     xlo = c - hw;
     xhi = c + hw;
     return true;
@@ -241,13 +245,20 @@ __device__ __forceinline__ uint32_t tight_slot_item(const TightG& g, uint32_t sl
     int lo[2], hi[2];
     if (slot < nrows) {
         const uint32_t ty = ra + slot;
+        if (ty >= nty || !wmain) return 0u;
+        // the two half strips of the tile row in sub-block columns of the (slab-clipped) rect; the row's run of tiles is the hull of
+        // the two intervals (E ∩ row strip is the union of its halves): no third strip, and one chord less than strip by strip
+        const int cmin = (int)(xa * ns), cmax = (int)((xa + wmain) * ns) - 1;
         const TightChord cb = tight_chord_at(g, tight_row_dy(g, ty, ts)), ca = tight_chord_at(g, tight_row_dy(g, ty + 1u, ts));
-        const uint32_t len = tight_row(g, ty, ts, inv_ts, nty, xa, wmain, 0u, cb, ca, r);
-        if (!len) return 0u;
-        const int cmin = r.tlo * (int)ns, cmax = (r.thi + 1) * (int)ns - 1;
         tight_substrips(g, ty, ts, sub, inv_sub, cmin, cmax, cb, ca, lo, hi);
-        w1 = ty | ((uint32_t)r.tlo << 8) | ((len - 1u) << 16);
-        w2 = tight_pack_intervals(lo, hi, cmin, len * ns);
+        int slo = cmax + 1, shi = cmin - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (lo[h] <= hi[h]) { slo = lo[h] < slo ? lo[h] : slo; shi = hi[h] > shi ? hi[h] : shi; }
+        if (slo > shi) return 0u;
+        const uint32_t tlo = (uint32_t)slo / ns, thi = (uint32_t)shi / ns, len = thi - tlo + 1u;
+        w1 = ty | (tlo << 8) | ((len - 1u) << 16);
+        w2 = tight_pack_intervals(lo, hi, (int)(tlo * ns), len * ns);
         return len;
     }
     if (!alias) return 0u;

@@ -7,7 +7,7 @@
 // leaves only the tile id for the stable instance binning.
 //
 // Round 2 fed this stage from a chained look-back scan that compacted the visible gaussians (31 us for 24 MB, bound by the
-// chain) and counted buckets over tiles of the COMPACTED list (4 launches, 85 us).  Here the tiles are chunks of 4096
+// chain) and counted buckets over tiles of the COMPACTED list (4 launches, 85 us).  Here the tiles are chunks of 2048
 // consecutive gaussian INDICES, so nothing has to be compacted or scanned beforehand and no workgroup waits for another:
 //   hist     every chunk counts the buckets of its visible gaussians      -> M[bucket][chunk] = (gaussians, quantity)
 //   rowscan  every bucket's row of M is scanned over the chunks (exclusive) -> row totals
@@ -20,7 +20,7 @@
 // All three are HBM-trivial (24-50 MB); what they cost is their launches.
 #include "gs_device.h"
 
-#define GC_ITEMS 16
+#define GC_ITEMS 8
 #define GC_THREADS 256
 #define GC (GC_THREADS * GC_ITEMS) // gaussian indices per chunk
 #define GBINS 1024                 // bucket = u32(min(50 depth, 999)) < 1000 (write_tile_ids.wgsl:31)
@@ -87,13 +87,22 @@ __device__ __forceinline__ GsPair block_excl2(GsPair v, uint32_t tid, GsPair* s_
     return r;
 }
 
-// One workgroup per 8 buckets (one 64-byte sector per chunk): thread (cl = t / 8, sub = t % 8) owns the chunks
-// [cl * per, (cl + 1) * per) of bucket 8 * blockIdx + sub; the 32 partial sums of a bucket are combined through LDS.
-__global__ __launch_bounds__(GC_THREADS) void gs_gsort_rowscan_kernel(uint2* __restrict__ M, uint32_t NT, uint32_t n, uint2* __restrict__ rowtot) {
-    __shared__ uint32_t s_x[32][8];
-    __shared__ unsigned long long s_y[32][8];
-    const uint32_t nt = (n + GC - 1) / GC, tid = threadIdx.x, cl = tid >> 3, sub = tid & 7u;
-    const uint32_t per = (nt + 31u) / 32u;
+// One workgroup of 1024 threads per 8 buckets (one 64-byte sector per chunk): thread (cl = t / 8, sub = t % 8) owns the chunks
+// [cl * per, (cl + 1) * per) of bucket 8 * blockIdx + sub -- a dozen at 6.1 M gaussians, two batches of independent loads; the
+// 128 partial sums of a bucket are scanned by lane shifts of 8 inside a wave and through LDS across the 16 waves.
+#define GR_THREADS 1024
+__device__ __forceinline__ void scan_stride8(uint32_t& x, unsigned long long& y, uint32_t lane) { // inclusive over lanes l, l-8, l-16, ...
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+        const uint32_t ox = __shfl_up(x, d, 64), lo = __shfl_up((uint32_t)y, d, 64), hi = __shfl_up((uint32_t)(y >> 32), d, 64);
+        if ((int)lane >= d) { x += ox; y += ((unsigned long long)hi << 32) | lo; }
+    }
+}
+__global__ __launch_bounds__(GR_THREADS) void gs_gsort_rowscan_kernel(uint2* __restrict__ M, uint32_t NT, uint32_t n, uint2* __restrict__ rowtot) {
+    __shared__ uint32_t s_x[GR_THREADS / 64][8];
+    __shared__ unsigned long long s_y[GR_THREADS / 64][8];
+    const uint32_t nt = (n + GC - 1) / GC, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, cl = tid >> 3, sub = tid & 7u;
+    const uint32_t per = (nt + GR_THREADS / 8 - 1u) / (GR_THREADS / 8);
     const uint32_t c0 = cl * per < nt ? cl * per : nt, c1 = (cl + 1u) * per < nt ? (cl + 1u) * per : nt;
     uint2* row = M + (uint64_t)blockIdx.x * NT * 8u + sub;
     uint32_t ax = 0;
@@ -105,15 +114,18 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_rowscan_kernel(uint2* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ax += v[k].x; ay += v[k].y; }
     }
-    s_x[cl][sub] = ax; s_y[cl][sub] = ay;
+    uint32_t ix = ax;
+    unsigned long long iy = ay;
+    scan_stride8(ix, iy, lane);
+    if (lane >= 56u) { s_x[w][sub] = ix; s_y[w][sub] = iy; } // the wave's total of each of its 8 sub-buckets
     __syncthreads();
-    uint32_t rx = 0, tx = 0;
-    unsigned long long ry = 0, ty = 0;
-#pragma unroll 8
-    for (uint32_t k = 0; k < 32u; ++k) {
+    uint32_t rx = ix - ax, tx = 0;
+    unsigned long long ry = iy - ay, ty = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < GR_THREADS / 64; ++k) {
         const uint32_t vx = s_x[k][sub];
         const unsigned long long vy = s_y[k][sub];
-        if (k < cl) { rx += vx; ry += vy; }
+        if (k < w) { rx += vx; ry += vy; }
         tx += vx; ty += vy;
     }
     for (uint32_t c = c0; c < c1; c += 8u) {
@@ -126,24 +138,29 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_rowscan_kernel(uint2* __r
             rx += v[k].x; ry += v[k].y;
         }
     }
-    if (cl == 0) rowtot[blockIdx.x * 8u + sub] = make_uint2(tx, sat32(ty));
+    if (tid < 8u) rowtot[blockIdx.x * 8u + sub] = make_uint2(tx, sat32(ty));
 }
 
 struct GsortShared {
     uint2 base[GBINS];                 // first sorted position / first quantity offset of (bucket, this chunk)
-    uint32_t binstart[GBINS];          // first slot of the bucket in the chunk's sorted order
-    uint32_t whist[GC / GBINS][GBINS]; // per-wave running counts while ranking ([wave][bucket]); then the prefix of the sorted quantities (GC words)
-    uint32_t id[GC], word[GC], aux[GC];
+    unsigned short binstart[GBINS];    // first slot of the bucket in the chunk's sorted order
+    union {
+        unsigned short whist[GC_THREADS / 64][GBINS]; // per-wave running counts while ranking ([wave][bucket]) ...
+        uint32_t P[GC];                               // ... then the prefix of the sorted quantities
+    } u;
+    unsigned short id[GC];             // index inside the chunk
+    uint32_t word[GC], aux[GC];
     GsPair w2[GC_THREADS / 64];
     uint32_t wcnt[GC_THREADS / 64];
 };
-static_assert(GC / GBINS == GC_THREADS / 64, "one ranking row per wave");
+static_assert(sizeof(unsigned short) * (GC_THREADS / 64) * GBINS == sizeof(uint32_t) * GC, "the ranking counters and the prefix share their storage");
 
 // Output: ONE 16-byte record per visible gaussian in (bucket, index) order -- {gaussian id, count word, exclusive prefix of the
 // quantity, aux} -- because a (chunk, bucket) run is about two gaussians long: four separate arrays were four scattered 4-byte
 // stores each (round 2), a record is one 16-byte store.  aux_in (optional, tight row pipeline): a second per-gaussian word
 // (the arena address of its row-item slots).  chunk_table[c] = the gaussian whose quantity interval holds c * 1024 (the
 // reference-binning emission and the row sort start there).  tot_*: visible gaussians, total quantity (saturated).
+// 38 KB of LDS: four workgroups per CU; every global load of the workgroup is issued before the first barrier.
 __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint32_t* __restrict__ words, const uint32_t* __restrict__ aux_in, uint32_t n,
                                                                       const uint2* __restrict__ M, uint32_t NT, const uint2* __restrict__ rowtot,
                                                                       uint4* __restrict__ grec, uint32_t* __restrict__ chunk_table,
@@ -155,33 +172,39 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     constexpr uint32_t BPT = GBINS / GC_THREADS; // buckets per thread (4 consecutive)
 
-    // ---- bucket bases: exclusive scan of the row totals, plus this chunk's entry of the scanned table ----
-    {
-        uint2 t[BPT];
-        GsPair acc; acc.x = 0u; acc.y = 0ull;
-#pragma unroll
-        for (uint32_t i = 0; i < BPT; ++i) { t[i] = rowtot[tid * BPT + i]; acc.x += t[i].x; acc.y += t[i].y; }
-        GsPair total;
-        GsPair run = block_excl2(acc, tid, S.w2, total);
-#pragma unroll
-        for (uint32_t i = 0; i < BPT; ++i) {
-            const uint32_t b = tid * BPT + i;
-            const uint2 m = M[m_index(b, chunk, NT)];
-            S.base[b] = make_uint2(run.x + m.x, sat32(run.y + m.y));
-            run.x += t[i].x; run.y += t[i].y;
-        }
-        if (chunk == 0 && tid == 0) { *tot_visible = total.x; *tot_quantity = sat32(total.y); }
-    }
-    for (uint32_t k = lane; k < GBINS; k += 64) S.whist[w][k] = 0u;
-
-    // ---- the chunk's visible gaussians, compacted in index order: wave w reads indices w*1024 + j*64 + lane ----
-    uint32_t wv[GC_ITEMS];
-    const uint32_t e0 = chunk * GC + w * (64 * GC_ITEMS) + lane;
-    uint32_t wave_vis = 0;
+    // ---- every global load up front: the chunk's count words (+ aux), the row totals, this chunk's entries of the table ----
+    uint32_t wv[GC_ITEMS], av[GC_ITEMS];
+    const uint32_t e0 = chunk * GC + w * (64 * GC_ITEMS) + lane; // wave w reads indices w * 512 + j * 64 + lane
 #pragma unroll
     for (int j = 0; j < GC_ITEMS; ++j) {
         const uint32_t k = e0 + j * 64;
         wv[j] = (k < n) ? words[k] : 0u;
+        av[j] = (aux_in && k < n) ? aux_in[k] : 0u;
+    }
+    uint2 t[BPT], mm[BPT];
+#pragma unroll
+    for (uint32_t i = 0; i < BPT; ++i) { t[i] = rowtot[tid * BPT + i]; mm[i] = M[m_index(tid * BPT + i, chunk, NT)]; }
+
+    // ---- bucket bases: exclusive scan of the row totals, plus this chunk's entry of the scanned table ----
+    {
+        GsPair acc; acc.x = 0u; acc.y = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < BPT; ++i) { acc.x += t[i].x; acc.y += t[i].y; }
+        GsPair total;
+        GsPair run = block_excl2(acc, tid, S.w2, total);
+#pragma unroll
+        for (uint32_t i = 0; i < BPT; ++i) {
+            S.base[tid * BPT + i] = make_uint2(run.x + mm[i].x, sat32(run.y + mm[i].y));
+            run.x += t[i].x; run.y += t[i].y;
+        }
+        if (chunk == 0 && tid == 0) { *tot_visible = total.x; *tot_quantity = sat32(total.y); }
+    }
+    for (uint32_t k = lane; k < GBINS; k += 64) S.u.whist[w][k] = 0;
+
+    // ---- the chunk's visible gaussians, compacted in index order ----
+    uint32_t wave_vis = 0;
+#pragma unroll
+    for (int j = 0; j < GC_ITEMS; ++j) {
         if (!(wv[j] & GS_COUNT_MASK)) wv[j] = 0u;
         wave_vis += (uint32_t)__popcll(__ballot(wv[j] != 0u));
     }
@@ -195,10 +218,9 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
         const unsigned long long bal = __ballot(wv[j] != 0u);
         if (wv[j]) {
             const uint32_t p = cbase + (uint32_t)__popcll(bal & lt_mask);
-            const uint32_t k = e0 + j * 64;
-            S.id[p] = k;
+            S.id[p] = (unsigned short)(w * (64 * GC_ITEMS) + j * 64 + lane);
             S.word[p] = wv[j];
-            if (aux_in) S.aux[p] = aux_in[k];
+            S.aux[p] = av[j];
         }
         cbase += (uint32_t)__popcll(bal);
     }
@@ -214,10 +236,10 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
 #pragma unroll
     for (int j = 0; j < GC_ITEMS; ++j) {
         const uint32_t p = w * Q + j * 64 + lane;
-        const bool in = (uint32_t)j < T; // (p < GC then: T*256 <= GC)
-        gid[j] = in ? S.id[p] : 0u;
+        const bool in = (uint32_t)j < T; // (p < GC then: T * 256 <= GC)
+        gid[j] = in ? (uint32_t)S.id[p] : 0u;
         wd[j] = in ? S.word[p] : 0xFFFFFFFFu;
-        ax[j] = (in && aux_in) ? S.aux[p] : 0u;
+        ax[j] = in ? S.aux[p] : 0u;
     }
     // peers = lanes holding the same bucket (10 ballots), order = (item, lane): stable
 #pragma unroll
@@ -235,11 +257,11 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
             }
             const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
             const uint32_t cnt = __popc(plo) + __popc(phi);
-            const uint32_t pre = S.whist[w][d];
+            const uint32_t pre = S.u.whist[w][d];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // every peer has read `pre` before the leader's store (one wave, in-order LDS)
-            if (below == 0) S.whist[w][d] = pre + cnt;
+            if (below == 0) S.u.whist[w][d] = (unsigned short)(pre + cnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t r = pre + below; // < 4096
+            const uint32_t r = pre + below; // < 2048
             if (j & 1) rank2[j >> 1] |= r << 16;
             else rank2[j >> 1] = r;
         }
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
             const uint32_t b = tid * BPT + i;
             uint32_t run = 0;
 #pragma unroll
-            for (int k = 0; k < GC_THREADS / 64; ++k) { const uint32_t t = S.whist[k][b]; S.whist[k][b] = run; run += t; }
+            for (int k = 0; k < GC_THREADS / 64; ++k) { const uint32_t c = S.u.whist[k][b]; S.u.whist[k][b] = (unsigned short)run; run += c; }
             tot[i] = run;
             acc += run;
         }
@@ -262,24 +284,31 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
         const GsPair ex = block_excl2(in, tid, S.w2, total);
         uint32_t run = ex.x;
 #pragma unroll
-        for (uint32_t i = 0; i < BPT; ++i) { S.binstart[tid * BPT + i] = run; run += tot[i]; }
+        for (uint32_t i = 0; i < BPT; ++i) { S.binstart[tid * BPT + i] = (unsigned short)run; run += tot[i]; }
     }
     __syncthreads();
     // ---- reorder through LDS (every thread holds its items in registers: the arrays can be overwritten) ----
+    uint32_t mypos[GC_ITEMS];
 #pragma unroll
     for (int j = 0; j < GC_ITEMS; ++j) {
+        mypos[j] = 0xFFFFFFFFu;
         if ((uint32_t)j < T) {
             const uint32_t d = wd[j] >> GS_COUNT_BITS;
             const uint32_t r = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
-            const uint32_t pos = S.binstart[d] + S.whist[w][d] + r;
-            S.id[pos] = gid[j];
-            S.word[pos] = wd[j];
-            S.aux[pos] = ax[j];
+            mypos[j] = (uint32_t)S.binstart[d] + (uint32_t)S.u.whist[w][d] + r;
+        }
+    }
+    __syncthreads(); // every wave has read the ranking counters: the prefix below overwrites them
+#pragma unroll
+    for (int j = 0; j < GC_ITEMS; ++j) {
+        if ((uint32_t)j < T) {
+            S.id[mypos[j]] = (unsigned short)gid[j];
+            S.word[mypos[j]] = wd[j];
+            S.aux[mypos[j]] = ax[j];
         }
     }
     __syncthreads();
-    // ---- exclusive scan of the quantities in sorted order (thread t: slots 16t .. 16t+15) ----
-    uint32_t* P = &S.whist[0][0]; // GC words: the ranking counters are dead now
+    // ---- exclusive scan of the quantities in sorted order (thread t: slots 8t .. 8t+7) ----
     {
         uint32_t c[GC_ITEMS];
         unsigned long long acc = 0;
@@ -294,9 +323,8 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
         in.x = 0u; in.y = acc;
         const GsPair ex = block_excl2(in, tid, S.w2, total);
         unsigned long long run = ex.y;
-        __syncthreads(); // (block_excl2 ends with a barrier; this one orders the reuse of whist as P for every wave)
 #pragma unroll
-        for (int j = 0; j < GC_ITEMS; ++j) { P[tid * GC_ITEMS + j] = sat32(run); run += c[j]; }
+        for (int j = 0; j < GC_ITEMS; ++j) { S.u.P[tid * GC_ITEMS + j] = sat32(run); run += c[j]; }
     }
     __syncthreads();
     // ---- store: coalesced over the sorted slots ----
@@ -308,9 +336,9 @@ __global__ __launch_bounds__(GC_THREADS) void gs_gsort_scatter_kernel(const uint
         const uint32_t b = x >> GS_COUNT_BITS, first = S.binstart[b];
         const uint2 base = S.base[b];
         const uint32_t g = base.x + (pos - first);
-        const unsigned long long off64 = (unsigned long long)base.y + (P[pos] - P[first]);
+        const unsigned long long off64 = (unsigned long long)base.y + (S.u.P[pos] - S.u.P[first]);
         const uint32_t off = sat32(off64);
-        grec[g] = make_uint4(S.id[pos], x, off, S.aux[pos]);
+        grec[g] = make_uint4(chunk * GC + (uint32_t)S.id[pos], x, off, S.aux[pos]);
         const uint32_t cnt = x & GS_COUNT_MASK; // > 0: only visible gaussians are here
         if (off != 0xFFFFFFFFu) {
             const unsigned long long lastq = (off64 + cnt - 1ull) >> GS_EMIT_CHUNK_SHIFT;
@@ -332,7 +360,7 @@ void gs_launch_gsort(const uint32_t* words, const uint32_t* aux_in, uint32_t n, 
     uint2* M = (uint2*)scratch;
     uint2* rowtot = M + (uint64_t)GBINS * NT;
     hipLaunchKernelGGL(gs_gsort_hist_kernel, dim3(NT), dim3(GC_THREADS), 0, st, words, n, M, NT);
-    hipLaunchKernelGGL(gs_gsort_rowscan_kernel, dim3(GBINS / 8), dim3(GC_THREADS), 0, st, M, NT, n, rowtot);
+    hipLaunchKernelGGL(gs_gsort_rowscan_kernel, dim3(GBINS / 8), dim3(GR_THREADS), 0, st, M, NT, n, rowtot);
     hipLaunchKernelGGL(gs_gsort_scatter_kernel, dim3(NT), dim3(GC_THREADS), 0, st, words, aux_in, n, (const uint2*)M, NT, (const uint2*)rowtot,
                        (uint4*)grec, chunk_table, chunk_cap, tot_visible, tot_quantity);
 }

@@ -184,10 +184,9 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
     __shared__ uint32_t s_ids[PRE_G * NB];
     __shared__ uint32_t s_cnt[2][4];
     __shared__ uint32_t s_misc[8];
-    // TIGHT: the row items of up to 256 survivors at a time are computed by the whole workgroup, one (survivor, slot) per
-    // thread and trip (a lane looping over its own rect's rows would wait for the tallest rect of its wave)
-    __shared__ float4 s_tA[TIGHT ? 256 : 1], s_tB[TIGHT ? 256 : 1], s_tC[TIGHT ? 256 : 1]; // gx gy cx cy | cz cxz lim2 rcx | xmax dyR eR mode
-    __shared__ uint32_t s_trow[TIGHT ? 256 : 1], s_tcol[TIGHT ? 256 : 1], s_trp[TIGHT ? 256 : 1], s_tcnt[TIGHT ? 256 : 1], s_tgid[TIGHT ? 256 : 1];
+    // TIGHT: per-survivor records of the row-item loop (written and read by the survivor's own wave)
+    __shared__ float4 s_tA[TIGHT ? 256 : 1], s_tB[TIGHT ? 256 : 1], s_tC[TIGHT ? 256 : 1]; // gx gy kc qa | qb rcx xmax dyR | eR mode rows cols
+    __shared__ uint32_t s_mark[TIGHT ? 256 : 1], s_tcnt[TIGHT ? 256 : 1], s_tgid[TIGHT ? 256 : 1];
     __shared__ uint32_t s_tw[4];
     __shared__ uint32_t s_rowhist[TIGHT ? 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -346,8 +345,10 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         }
         uint32_t nslots = 0, rowptr = 0;
         if (TIGHT) {
-            if (trip) __syncthreads(); // the previous trip's slot items are done with the LDS records
-            uint32_t ra = 0;
+            // The slots of a wave's 64 survivors are computed by THAT wave, one (survivor, slot) per lane and trip of the loop
+            // below: the per-survivor records in LDS are written and read by one wave only (no workgroup barrier inside the
+            // loop), and a lane looping over its own rect's rows would wait for the tallest rect of its wave.
+            uint32_t ra = 0, nrows = 0;
             if (active && count) {
                 opacity = sigmoid_ref(so.w);
                 const TightG tg = tight_setup(uvx, uvy, conx, cony, conz, opacity, (float)f.width, (float)f.height);
@@ -355,13 +356,13 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
                 else {
                     uint32_t rb;
                     tight_rows(tg, rminy, rmaxy, f.tile_size, inv_ts, f.nty, t_alias, ra, rb);
-                    nslots = (rb - ra) * (1u + t_alias);
+                    nrows = rb - ra;
+                    nslots = nrows * (1u + t_alias);
                     if (!nslots) count = 0u;
-                    s_tA[tid] = make_float4(tg.gx, tg.gy, tg.cx, tg.cy);
-                    s_tB[tid] = make_float4(tg.cz, tg.cxz, tg.lim2, tg.rcx);
-                    s_tC[tid] = make_float4(tg.xmax, tg.dyR, tg.eR, __uint_as_float(tg.mode));
-                    s_trow[tid] = ra | ((rb - ra) << 16);
-                    s_tcol[tid] = t_xa | (t_wmain << 16) | (t_alias << 31);
+                    s_tA[tid] = make_float4(tg.gx, tg.gy, tg.kc, tg.qa);
+                    s_tB[tid] = make_float4(tg.qb, tg.rcx, tg.xmax, tg.dyR);
+                    s_tC[tid] = make_float4(tg.eR, __uint_as_float(tg.mode), __uint_as_float(ra | (nrows << 16)),
+                                            __uint_as_float(t_xa | (t_wmain << 16) | (t_alias << 31)));
                     s_tgid[tid] = i;
                 }
             } else {
@@ -369,13 +370,13 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             }
             s_tcnt[tid] = 0u;
             const uint32_t rincl = wave_incl_scan(nslots, lane);
+            const uint32_t Rw = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63); // slots of this wave's survivors
+            const uint32_t myrp = rincl - nslots;
             if (lane == 63) s_tw[w] = rincl;
             __syncthreads();
             uint32_t wbase = 0, R = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { if (k < (int)w) wbase += s_tw[k]; R += s_tw[k]; }
-            const uint32_t myrp = wbase + rincl - nslots;
-            s_trp[tid] = myrp;
             if (tid == 0) { // this trip's slots: one bump of the shard's cursor
                 uint32_t at = 0, ok = 1u;
                 if (R) {
@@ -385,37 +386,49 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
                 s_misc[2] = at; s_misc[3] = ok;
             }
             __syncthreads();
-            const uint32_t abase = shard * shard_cap + s_misc[2];
+            const uint32_t abase = shard * shard_cap + s_misc[2] + wbase;
             const bool ok = s_misc[3] != 0u;
-            for (uint32_t ri = tid; ri < R; ri += 256) {
-                uint32_t j = 0; // largest j with rp[j] <= ri (slot-less survivors share their successor's prefix)
-#pragma unroll
-                for (int step = 128; step >= 1; step >>= 1) {
-                    const uint32_t m = j + step;
-                    if (m < 256u && s_trp[m] <= ri) j = m;
-                }
-                const float4 a = s_tA[j], b = s_tB[j], c4 = s_tC[j];
-                TightG g;
-                g.gx = a.x; g.gy = a.y; g.cx = a.z; g.cy = a.w; g.cz = b.x; g.cxz = b.y; g.lim2 = b.z; g.rcx = b.w;
-                g.xmax = c4.x; g.dyR = c4.y; g.eR = c4.z; g.mode = __float_as_uint(c4.w); g.ymax = 0.0f;
-                const uint32_t cw = s_tcol[j], rw = s_trow[j];
-                uint32_t w1, w2;
-                const uint32_t ilen = tight_slot_item(g, ri - s_trp[j], rw & 0xFFFFu, rw >> 16, f.tile_size, inv_ts, sub, inv_sub, ns, f.nty, cw & 0xFFFFu,
-                                                      (cw >> 16) & 0x7FFFu, cw >> 31, w1, w2);
-                if (ilen) {
-                    atomicAdd(&s_tcnt[j], ilen);
-                    atomicAdd(&s_rowhist[w1 & 0xFFu], 1u);
-                }
-                if (ok) {
-                    gs_row_u32x3 it;
-                    it.x = ilen ? s_tgid[j] : GS_ROW_HOLE; it.y = w1; it.z = w2;
-                    *reinterpret_cast<gs_row_u32x3*>(to.arena + (uint64_t)(abase + ri) * 3u) = it;
+            uint32_t jcarry = 0u; // owner (+1) of the slot just before the batch
+            for (uint32_t rb0 = 0; rb0 < Rw; rb0 += 64u) {
+                // owner of a slot = the survivor whose slots [myrp, myrp + nslots) hold it: every survivor with slots marks the batch
+                // position of its first one, a running maximum (DPP) spreads the marks
+                s_mark[tid] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (nslots && myrp >= rb0 && myrp < rb0 + 64u) s_mark[(w << 6) + (myrp - rb0)] = lane + 1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t m = wave_incl_max(s_mark[tid]);
+                m = m > jcarry ? m : jcarry;
+                jcarry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+                const uint32_t ri = rb0 + lane;
+                const uint32_t rpj = (uint32_t)__shfl((int)myrp, (int)(m ? m - 1u : 0u), 64); // (every lane takes part: the loop is wave-uniform)
+                if (ri < Rw) {
+                    const uint32_t j = (w << 6) + (m - 1u);
+                    const float4 a = s_tA[j], b = s_tB[j], c4 = s_tC[j];
+                    TightG g;
+                    g.gx = a.x; g.gy = a.y; g.kc = a.z; g.qa = a.w; g.qb = b.x; g.rcx = b.y; g.xmax = b.z; g.dyR = b.w;
+                    g.eR = c4.x; g.mode = __float_as_uint(c4.y);
+                    g.cx = g.cy = g.cz = g.cxz = g.lim2 = g.ymax = 0.0f; // (setup only)
+                    const uint32_t rw = __float_as_uint(c4.z), cw = __float_as_uint(c4.w);
+                    uint32_t w1, w2;
+                    const uint32_t ilen = tight_slot_item(g, ri - rpj, rw & 0xFFFFu, rw >> 16, f.tile_size, inv_ts, sub, inv_sub, ns, f.nty, cw & 0xFFFFu,
+                                                          (cw >> 16) & 0x7FFFu, cw >> 31, w1, w2);
+                    if (ilen) {
+                        atomicAdd(&s_tcnt[j], ilen);
+                        atomicAdd(&s_rowhist[w1 & 0xFFu], 1u);
+                    }
+                    if (ok) {
+                        gs_row_u32x3 it;
+                        it.x = ilen ? s_tgid[j] : GS_ROW_HOLE; it.y = w1; it.z = w2;
+                        *reinterpret_cast<gs_row_u32x3*>(to.arena + (uint64_t)(abase + ri) * 3u) = it;
+                    }
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (count) count = ok ? s_tcnt[tid] : 0u;
             rowptr = abase + myrp;
-            if (!active) continue; // (after the last barrier of the trip)
+            if (!active) continue;
         }
         // low 22 bits: tile count (TIGHT: row-item slots); high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
         const uint32_t bucket = f2u_sat(wg_min(50.0f * pv[2], 999.0f));

@@ -29,10 +29,10 @@
 
 typedef uint32_t gs_item3 __attribute__((ext_vector_type(3), aligned(4)));
 
-#define RA_ITEMS 12
+#define RA_ITEMS 8
 #define RA_WAVES 4
 #define RA_THREADS (RA_WAVES * 64)
-#define RA_TILE (RA_THREADS * RA_ITEMS) // 3072 slots per tile: 36 KB of LDS for the reorder, three workgroups per CU
+#define RA_TILE (RA_THREADS * RA_ITEMS) // 2048 slots per tile: 24 KB of LDS for the reorder, five workgroups per CU
 #define RA_AGG (1u << 30)
 #define RA_PREFIX (2u << 30)
 #define RA_FLAGS (3u << 30)
@@ -455,11 +455,26 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
     }
     uint32_t nch = S.T.cbase[256];
     if (nch > chunk_cap) nch = chunk_cap;
+    // The global loads of a chunk (its items, the column's start and earlier-chunk count) are issued one chunk AHEAD: a chunk is
+    // a dozen short barrier-separated phases, and with the loads at its head every one of them waited for HBM first.
+    gs_item3 nit[RB_IT];
+    uint32_t n_r = 0, n_ni = 0, n_tstart = 0, n_done = 0;
+    auto prefetch = [&](uint32_t c) {
+        n_r = row_of_chunk(S.T, c);
+        const uint32_t i0 = S.T.ibase[n_r] + (c - S.T.cbase[n_r]) * RB_CH;
+        const uint32_t i1 = (i0 + RB_CH < S.T.ibase[n_r + 1]) ? i0 + RB_CH : S.T.ibase[n_r + 1];
+        n_ni = i1 - i0;
+#pragma unroll
+        for (int k = 0; k < (int)RB_IT; ++k) {
+            const uint32_t e = tid * RB_IT + k;
+            nit[k] = *reinterpret_cast<const gs_item3*>(rows + (uint64_t)(i0 + (e < n_ni ? e : 0u)) * 3u);
+        }
+        n_tstart = S.rbase[n_r] + tileoff[n_r * 256u + tid];
+        n_done = M3[(uint64_t)c * 256u + tid];
+    };
+    if (blockIdx.x < nch) prefetch(blockIdx.x);
     for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
-        const uint32_t r = row_of_chunk(S.T, c);
-        const uint32_t i0 = S.T.ibase[r] + (c - S.T.cbase[r]) * RB_CH;
-        const uint32_t i1 = (i0 + RB_CH < S.T.ibase[r + 1]) ? i0 + RB_CH : S.T.ibase[r + 1];
-        const uint32_t ni = i1 - i0;
+        const uint32_t ni = n_ni;
         // ---- the chunk's items (thread t: RB_IT consecutive ones) and the prefix of their lengths ----
         uint32_t len[RB_IT], lsum = 0;
 #pragma unroll
@@ -467,12 +482,14 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             const uint32_t e = tid * RB_IT + k;
             len[k] = 0u;
             if (e < ni) {
-                const gs_item3 v = *reinterpret_cast<const gs_item3*>(rows + (uint64_t)(i0 + e) * 3u);
-                S.w0[e] = v.x; S.w1[e] = v.y; S.w2[e] = v.z;
-                len[k] = ((v.y >> 16) & 0xFFu) + 1u;
+                S.w0[e] = nit[k].x; S.w1[e] = nit[k].y; S.w2[e] = nit[k].z;
+                len[k] = ((nit[k].y >> 16) & 0xFFu) + 1u;
             }
             lsum += len[k];
         }
+        const uint32_t tstart = n_tstart; // first list slot of column `tid` for this chunk: tile start ...
+        uint32_t done = n_done;           // ... + what the row's earlier chunks put there
+        if (c + gridDim.x < nch) prefetch(c + gridDim.x);
         {
             const uint32_t incl = wave_incl_scan(lsum, lane);
             if (lane == 63) S.wsum[w] = incl;
@@ -485,9 +502,6 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             for (int k = 0; k < (int)RB_IT; ++k) { S.x.e.P[tid * RB_IT + k] = run; run += len[k]; }
             if (tid == 0) { S.x.e.P[RB_CH] = all; S.total = all; }
         }
-        // first list slot of column `tid` for this chunk: tile start + what the row's earlier chunks put there
-        const uint32_t tstart = S.rbase[r] + tileoff[r * 256u + tid];
-        uint32_t done = M3[(uint64_t)c * 256u + tid];
         __syncthreads();
         const uint32_t ninst = S.total;
         for (uint32_t s0 = 0; s0 < ninst; s0 += RB_SB) {
@@ -638,13 +652,13 @@ __global__ __launch_bounds__(256) void gs_rows_rebuild_keys_kernel(const uint32_
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_rows_sort_tiles(uint64_t row_cap) { return (uint32_t)((row_cap + RA_TILE - 1) / RA_TILE); }
 uint32_t gs_rows_chunks(uint64_t row_cap) { return (uint32_t)(row_cap / RB_CH + 256u); }
-// cus: compute units (grids are sized by residency: three workgroups of the sort, six of the expansion, eight of the count fit a CU)
+// cus: compute units (grids are sized by residency: five workgroups of the sort, six of the expansion, eight of the count fit a CU)
 void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chunk_table, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
                     uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
                     uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg) {
     const uint32_t chunk_cap = gs_rows_chunks(row_cap);
     if (!cus) cus = 1;
-    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
+    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 5u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
                        row_cap);
     if (mark) mark(mark_arg, 3);
     hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * 8u), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
