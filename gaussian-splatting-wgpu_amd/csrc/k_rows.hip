@@ -29,10 +29,10 @@
 
 typedef uint32_t gs_item3 __attribute__((ext_vector_type(3), aligned(4)));
 
-#define RA_ITEMS 8
-#define RA_WAVES 4
+#define RA_ITEMS 6
+#define RA_WAVES 8
 #define RA_THREADS (RA_WAVES * 64)
-#define RA_TILE (RA_THREADS * RA_ITEMS) // 2048 slots per tile: 24 KB of LDS for the reorder, five workgroups per CU
+#define RA_TILE (RA_THREADS * RA_ITEMS) // 3072 slots per tile (8 waves x 6 items per lane): 36 KB of LDS for the reorder, three workgroups (24 waves) per CU
 #define RA_AGG (1u << 30)
 #define RA_PREFIX (2u << 30)
 #define RA_FLAGS (3u << 30)
@@ -69,8 +69,11 @@ struct RowSortShared {
 // marks its first slot in LDS and a running maximum (DPP) hands every slot its owner.
 __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t* __restrict__ arena, const uint4* __restrict__ grec,
                                                                   const uint32_t* __restrict__ chunk_table, uint32_t* __restrict__ rows_out,
-                                                                  GsControl* ctl, uint32_t* __restrict__ status, uint32_t row_cap) {
+                                                                  GsControl* ctl, uint32_t* __restrict__ status, uint32_t row_cap, uint32_t ndig) {
+    // ndig: tile rows of the canvas = digits that exist; holes take digit `hole` (127 when the rows fit 7 bits: one ballot less)
     __shared__ RowSortShared sh;
+    const uint32_t hole = ndig < 128u ? 127u : 255u;
+    const int nbits = ndig < 128u ? 7 : 8;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t n = ctl->num_slots;
@@ -78,13 +81,13 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
     const uint32_t ntiles = (n + RA_TILE - 1) / RA_TILE;
     const uint32_t nvis = ctl->num_visible;
     {   // first slot of every tile row's run: exclusive scan of the digit histogram (every workgroup for itself)
-        const uint32_t c = gs_rowhist(ctl, tid);
+        const uint32_t c = tid < 256u ? gs_rowhist(ctl, tid) : 0u;
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) sh.wsum[w] = incl;
         __syncthreads();
         uint32_t b = 0;
         for (uint32_t k = 0; k < w; ++k) b += sh.wsum[k];
-        sh.dbase[tid] = b + incl - c;
+        if (tid < 256u) sh.dbase[tid] = b + incl - c;
         __syncthreads();
     }
     for (;;) {
@@ -137,26 +140,28 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
             }
         }
         for (uint32_t k = lane; k < 256; k += 64) sh.hist[w][k] = 0;
-        sh.tot[tid] = 0u;
+        if (tid < 256u) sh.tot[tid] = 0u;
         __syncthreads();
-        // holes (and the slots past the end) take digit 255, which no tile row has (nty <= 255): they rank last and are not stored
+        // holes (and the slots past the end) take a digit no tile row has: they rank last and are not stored
 #pragma unroll
-        for (int j = 0; j < RA_ITEMS; ++j) atomicAdd(&sh.tot[ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu)], 1u);
+        for (int j = 0; j < RA_ITEMS; ++j) atomicAdd(&sh.tot[ix[j] == GS_ROW_HOLE ? hole : (iy[j] & 0xFFu)], 1u);
         __syncthreads();
         // the tile's digit counts are published BEFORE the ranking: successors rarely meet an unpublished word
-        st_agent(status + (uint64_t)tile * 256 + tid, (tile == 0 ? RA_PREFIX : RA_AGG) | sh.tot[tid]);
+        if (tid < ndig) st_agent(status + (uint64_t)tile * 256 + tid, (tile == 0 ? RA_PREFIX : RA_AGG) | sh.tot[tid]);
         // rank inside the wave: peers = lanes holding the same digit (8 ballots), order = (item, lane)
 #pragma unroll
         for (int j = 0; j < RA_ITEMS; ++j) {
-            const uint32_t d = ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu);
+            const uint32_t d = ix[j] == GS_ROW_HOLE ? hole : (iy[j] & 0xFFu);
             uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                const uint32_t bit = (d >> b) & 1u;
-                const unsigned long long bal = __ballot(bit != 0u);
-                const uint32_t inv = bit - 1u;
-                plo &= (uint32_t)bal ^ inv;
-                phi &= (uint32_t)(bal >> 32) ^ inv;
+                if (b < nbits) {
+                    const uint32_t bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit != 0u);
+                    const uint32_t inv = bit - 1u;
+                    plo &= (uint32_t)bal ^ inv;
+                    phi &= (uint32_t)(bal >> 32) ^ inv;
+                }
             }
             const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
             const uint32_t cnt = __popc(plo) + __popc(phi);
@@ -169,40 +174,43 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
             else rank2[j >> 1] = r;
         }
         __syncthreads();
-        // thread d: counts of digit d per wave -> exclusive offsets across waves, tile total; look-back over the predecessors
-        uint32_t cw[RA_WAVES], total = 0, excl = 0;
+        // thread d < 256: counts of digit d per wave -> exclusive offsets across waves, tile total; look-back over the predecessors
+        // (only the digits that exist: a canvas has `ndig` tile rows, 68 of 256 at 1080p)
+        uint32_t cw[RA_WAVES], total = 0, excl = 0, incl = 0;
+        if (tid < 256u) {
 #pragma unroll
-        for (int k = 0; k < RA_WAVES; ++k) { cw[k] = sh.hist[k][tid]; total += cw[k]; }
-        const uint32_t incl = wave_incl_scan(total, lane);
-        if (lane == 63) sh.wsum[w] = incl;
-        if (tile > 0) {
-            constexpr int LB = 8;
-            bool found = false;
-            for (int t = (int)tile - 1; t >= 0 && !found; t -= LB) {
-                uint32_t sv[LB];
+            for (int k = 0; k < RA_WAVES; ++k) { cw[k] = sh.hist[k][tid]; total += cw[k]; }
+            incl = wave_incl_scan(total, lane);
+            if (lane == 63) sh.wsum[w] = incl;
+            if (tile > 0 && tid < ndig) {
+                constexpr int LB = 8;
+                bool found = false;
+                for (int t = (int)tile - 1; t >= 0 && !found; t -= LB) {
+                    uint32_t sv[LB];
 #pragma unroll
-                for (int k = 0; k < LB; ++k) sv[k] = (t - k >= 0) ? ld_agent(status + (uint64_t)(t - k) * 256 + tid) : RA_PREFIX;
+                    for (int k = 0; k < LB; ++k) sv[k] = (t - k >= 0) ? ld_agent(status + (uint64_t)(t - k) * 256 + tid) : RA_PREFIX;
 #pragma unroll
-                for (int k = 0; k < LB; ++k) {
-                    if (found) break;
-                    uint32_t v = sv[k], spins = 0;
-                    while ((v & RA_FLAGS) == 0 && ++spins < GS_SPIN_LIMIT) { // not published yet: poll this one word
-                        __builtin_amdgcn_s_sleep(1);
-                        v = ld_agent(status + (uint64_t)(t - k) * 256 + tid);
+                    for (int k = 0; k < LB; ++k) {
+                        if (found) break;
+                        uint32_t v = sv[k], spins = 0;
+                        while ((v & RA_FLAGS) == 0 && ++spins < GS_SPIN_LIMIT) { // not published yet: poll this one word
+                            __builtin_amdgcn_s_sleep(1);
+                            v = ld_agent(status + (uint64_t)(t - k) * 256 + tid);
+                        }
+                        if ((v & RA_FLAGS) == 0) { ctl->fault = 1u; found = true; break; }
+                        excl += v & RA_VALUE;
+                        if ((v & RA_FLAGS) == RA_PREFIX) found = true;
                     }
-                    if ((v & RA_FLAGS) == 0) { ctl->fault = 1u; found = true; break; }
-                    excl += v & RA_VALUE;
-                    if ((v & RA_FLAGS) == RA_PREFIX) found = true;
                 }
+                st_agent(status + (uint64_t)tile * 256 + tid, RA_PREFIX | ((excl + total) & RA_VALUE));
             }
-            st_agent(status + (uint64_t)tile * 256 + tid, RA_PREFIX | ((excl + total) & RA_VALUE));
         }
         __syncthreads();
-        {
+        if (tid < 256u) {
             uint32_t wv = 0;
             for (uint32_t k = 0; k < w; ++k) wv += sh.wsum[k];
             uint32_t run = wv + incl - total; // first position of digit `tid` in the tile's sorted order
-            if (tid == 255u) sh.nvalid = run; // the holes start here
+            if (tid == hole) sh.nvalid = run; // the holes start here (no digit above `hole` occurs)
             sh.gbase[tid] = sh.dbase[tid] + excl - run;
 #pragma unroll
             for (int k = 0; k < RA_WAVES; ++k) { sh.hist[k][tid] = run; run += cw[k]; }
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < RA_ITEMS; ++j) {
-            const uint32_t d = ix[j] == GS_ROW_HOLE ? 255u : (iy[j] & 0xFFu);
+            const uint32_t d = ix[j] == GS_ROW_HOLE ? hole : (iy[j] & 0xFFu);
             const uint32_t r = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
             const uint32_t pos = sh.hist[w][d] + r;
             sh.u.it[pos * 3 + 0] = ix[j];
@@ -410,6 +418,8 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t ns = f.tile_size >= 16u ? 2u : 1u;
+    const uint32_t hole = f.ntx < 128u ? 127u : 255u; // the digit of the slots past a sub-batch's end: no tile column has it
+    const int nbits = f.ntx < 128u ? 7 : 8;
     row_tables(S.T, ctl, tid);
     {   // first instance of every tile row
         const uint32_t v = tid < f.nty ? rowtot[tid] : 0u;
@@ -551,13 +561,18 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             uint32_t rank2[RB_PER / 2u];
 #pragma unroll
             for (int j = 0; j < (int)(RB_PER / 4u); ++j) col4[j] = 0u;
+            // this wave's batches of 64 slots that hold an instance (the rest of its RB_PER are skipped: a chunk averages two
+            // thirds of a sub-batch)
+            const uint32_t wfirst = s0 + w * RB_WSL;
+            const uint32_t jn = wfirst >= ninst ? 0u : ((ninst - wfirst + 63u) / 64u < RB_PER ? (ninst - wfirst + 63u) / 64u : RB_PER);
 #pragma unroll
             for (int j = 0; j < (int)RB_PER; ++j) {
+                if ((uint32_t)j >= jn) break;
                 const uint32_t sp = w * RB_WSL + j * 64u + lane, x = s0 + sp;
                 uint32_t m = wave_incl_max((uint32_t)S.x.e.mark[sp]);
                 m = m > carry ? m : carry;
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
-                uint32_t d = 255u;
+                uint32_t d = hole;
                 val[j] = 0u;
                 if (x < ninst) {
                     const uint32_t e = m - 1u;
@@ -567,18 +582,21 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
                 }
                 col4[j >> 2] |= d << (8 * (j & 3));
             }
-            // ---- rank by column inside the wave (slots past the end take digit 255: no tile column has it, ntx <= 255) ----
+            // ---- rank by column inside the wave (slots past the end take the digit `hole`) ----
 #pragma unroll
             for (int j = 0; j < (int)RB_PER; ++j) {
+                if ((uint32_t)j >= jn) break;
                 const uint32_t d = (col4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
 #pragma unroll
                 for (int b = 0; b < 8; ++b) {
-                    const uint32_t bit = (d >> b) & 1u;
-                    const unsigned long long bal = __ballot(bit != 0u);
-                    const uint32_t inv = bit - 1u;
-                    plo &= (uint32_t)bal ^ inv;
-                    phi &= (uint32_t)(bal >> 32) ^ inv;
+                    if (b < nbits) {
+                        const uint32_t bit = (d >> b) & 1u;
+                        const unsigned long long bal = __ballot(bit != 0u);
+                        const uint32_t inv = bit - 1u;
+                        plo &= (uint32_t)bal ^ inv;
+                        phi &= (uint32_t)(bal >> 32) ^ inv;
+                    }
                 }
                 const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
                 const uint32_t cnt = __popc(plo) + __popc(phi);
@@ -603,7 +621,7 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if (k < (int)w) b += S.wsum[4 + k];
                 uint32_t run = b + incl - total;
-                if (tid == 255u) S.nvalid = run;
+                if (tid == hole) S.nvalid = run;
                 S.gbase[tid] = tstart + done - run; // (wraps are harmless: only gbase + position is used, and it is bounds-checked)
                 done += total;
 #pragma unroll
@@ -612,6 +630,7 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < (int)RB_PER; ++j) {
+                if ((uint32_t)j >= jn) break;
                 const uint32_t d = (col4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 const uint32_t rr = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
                 const uint32_t pos = S.hist[w][d] + rr;
@@ -652,14 +671,14 @@ __global__ __launch_bounds__(256) void gs_rows_rebuild_keys_kernel(const uint32_
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_rows_sort_tiles(uint64_t row_cap) { return (uint32_t)((row_cap + RA_TILE - 1) / RA_TILE); }
 uint32_t gs_rows_chunks(uint64_t row_cap) { return (uint32_t)(row_cap / RB_CH + 256u); }
-// cus: compute units (grids are sized by residency: five workgroups of the sort, six of the expansion, eight of the count fit a CU)
+// cus: compute units (grids are sized by residency: three 8-wave workgroups of the sort, five of the expansion, eight of the count fit a CU)
 void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chunk_table, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
                     uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
                     uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg) {
     const uint32_t chunk_cap = gs_rows_chunks(row_cap);
     if (!cus) cus = 1;
-    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 5u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
-                       row_cap);
+    hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
+                       row_cap, f.nty);
     if (mark) mark(mark_arg, 3);
     hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * 8u), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
     hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap);
