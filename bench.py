@@ -38,14 +38,13 @@ CONFIGS = {
 
 
 def algorithmic_bytes(st, W, H, T):
-    """SURVEY.md 8(d) per-frame algorithmic bytes, per stage."""
+    """SURVEY.md 8(d) per-frame algorithmic bytes, per stage, verbatim: N gaussians, Nv visible, I instances, Ip staged entries, T
+    tiles, P pixels, p = sort passes over the INSTANCES the build really executes (the tight row pipeline writes every instance
+    once: p = 1; its pass over the row items is moved bytes of "emit", below, not algorithmic bytes)."""
     N, Nv, I, Ip, p = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"]
-    # depth-ordered pipeline: the scan stage also compacts the visible gaussians (8 B), sorts them by depth bucket
-    # (2 digits: (4 + 16*2) B) and scans their counts in that order (12 B), all per VISIBLE gaussian
-    extra = (8 + 36 + 12) * Nv if st.get("depth_ordered") else 0
     return {
         "preprocess": 12 * (N - Nv) + 236 * Nv + 4 * N + 56 * Nv,
-        "scan": 8 * N + extra,
+        "scan": 8 * N,
         "emit": 24 * Nv + 8 * I,
         "sort": (4 + 16 * p) * I,
         "ranges": 4 * I + 4 * T,
@@ -54,27 +53,36 @@ def algorithmic_bytes(st, W, H, T):
 
 
 def moved_bytes(st, W, H, T, tile16):
-    """What THIS build's kernels read + write per frame (beside SURVEY 8(d)'s reference-equivalent figures), depth-ordered
-    pipeline on 16-bit tile ids: projection reads the 12-byte position and, of a visible gaussian, its whole 256-byte record,
-    writes the 64-byte GaussianData and the count word; the scan stage reads the N count words, writes the compacted (bucket,
-    id, word) of the visible ones and counting-sorts them (hist 4, scatter 8 + 12, bucket table ~8 MB); the emission reads
-    48 bytes of GaussianData + 12 per visible gaussian and writes 6 bytes per instance; each sweep moves 12 bytes per pair;
-    ranges read 2 bytes per instance; the blend reads 4 bytes per staged entry per walker that stages it (<= 4) and 40 bytes
-    of GaussianData per (walker, entry) it evaluates, and writes 4 bytes per pixel."""
+    """What THIS build's kernels read + write per frame (beside SURVEY 8(d)'s figures).
+    Tight row pipeline (S row-item slots, R row items, NT = N / 2048 sort chunks, C = R / 512 + rows expansion chunks):
+    projection reads the 12-byte position of every gaussian and 32 + 192 bytes of a visible one, writes the count word, the 64-byte
+    GaussianData, the arena address and 12 bytes per slot; the gaussian-level sort reads the count words twice and the addresses once,
+    writes / scans / reads its 8 KB-per-chunk table and writes a 16-byte record per visible gaussian; the row sort reads those and
+    the slots and writes 12 bytes per item; count / scan / expansion read the items twice, a 1 KB table per chunk three times and
+    write 4 bytes per instance (and the ranges); the blend reads 4 bytes per staged entry per walker that stages it (<= 4) and 40
+    bytes of GaussianData per (walker, entry) it evaluates, and writes 4 bytes per pixel.
+    Reference binning, depth-ordered on 16-bit tile ids: as round 2 (emission 6 bytes per instance, 12 per pair and sweep)."""
     N, Nv, I, Ip, p, Ev = st["num_gaussians"], st["num_visible"], st["num_intersections"], st["num_processed"], st["sort_passes"], st["num_evaluated"]
+    if st.get("tight_binning"):
+        S, R = st["num_row_slots"], st["num_row_items"]
+        NT, C = (N + 2047) // 2048, R // 512 + H // 16 + 1
+        return {"preprocess": 12 * N + 224 * Nv + 4 * N + 68 * Nv + 12 * S, "scan": 12 * N + 4 * 8192 * NT + 16 * Nv,
+                "emit": 16 * Nv + 12 * S + 12 * R, "sort": 24 * R + 3 * 1024 * C + 4 * I + 4 * T, "ranges": 0,
+                "blend": 16 * Ip + 40 * Ev + 4 * W * H}
     if st.get("depth_ordered") and tile16:
-        return {"preprocess": 12 * N + 256 * Nv + 4 * N + 64 * Nv, "scan": 4 * N + 12 * Nv + (4 + 8 + 12) * Nv + 8 * (1 << 20),
-                "emit": 60 * Nv + 6 * I, "sort": 12 * p * I, "ranges": 2 * I + 4 * T, "blend": 16 * Ip + 40 * Ev + 4 * W * H}
+        NT = (N + 2047) // 2048
+        return {"preprocess": 12 * N + 224 * Nv + 4 * N + 64 * Nv, "scan": 8 * N + 4 * 8192 * NT + 16 * Nv,
+                "emit": 64 * Nv + 6 * I, "sort": 12 * p * I, "ranges": 2 * I + 4 * T, "blend": 16 * Ip + 40 * Ev + 4 * W * H}
     return None
 
 
-STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_scan_kernel"], "emit": ["gs_emit_tight_kernel", "gs_emit_balanced_kernel", "gs_emit_kernel"],
-                 "sort": ["gs_sort_sweep_kernel<unsigned short>", "gs_sort_sweep_kernel<unsigned int>", "gs_sort_sweep_kernel"],
+STAGE_KERNELS = {"preprocess": ["gs_preprocess_kernel"], "scan": ["gs_gsort_scatter_kernel", "gs_scan_kernel"], "emit": ["gs_rows_sort_kernel", "gs_emit_balanced_kernel", "gs_emit_kernel"],
+                 "sort": ["gs_rows_expand_kernel", "gs_sort_sweep_kernel<unsigned short>", "gs_sort_sweep_kernel<unsigned int>", "gs_sort_sweep_kernel"],
                  "ranges": ["gs_ranges16_kernel", "gs_ranges_kernel"],
                  "blend": ["gs_blend_quad_kernel", "gs_blend_wave_kernel", "gs_blend_kernel"]}
 
 
-PMC_FILE = os.path.join("profiles", "r02_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
 
 
 def pmc_traffic(stage, workload):
@@ -189,6 +197,41 @@ def self_check(gsplat, _abi, r, W, H, ts, device, u_last, args):
     return {"frame_verified": ok, "frame_verified_detail": detail,
             name: {"value": other_fps, "unit": "frames/s", "steps": k, "note": "same scene and orbit, the other blend mode, short loop outside the timed region"}}
 
+
+
+def reference_binning_leg(gsplat, _abi, r, W, H, ts, device, uniforms, args, eflag):
+    """Outside the timed region (N = 1): the same scene, orbit and blend mode rendered with the REFERENCE's binning (every tile of the
+    3-sigma rect, process_gaussians.wgsl:74-86) in the reference's emission order (gaussian index, full-key sort): the like-for-like
+    figure beside `value`, whose tight row pipeline bins a provably harmless subset of those instances.  Byte-equal frames in the
+    exact blend mode (self_check, tests/test_gpu_scale.py)."""
+    pg = gsplat.PackedGaussians.__new__(gsplat.PackedGaussians)
+    pg.numGaussians, pg.gaussiansBuffer = r.numGaussians, None
+    o = gsplat.Renderer(gsplat.Canvas(W, H), None, device, pg, ts, flags=eflag, share_with=r)
+    o.set_option(_abi.GS_OPT_TILE_CULL, 0)
+    o.set_option(_abi.GS_OPT_EMIT_ORDER, 1)
+    out = {"binning": "reference rect, gaussian-index emission order, full-key sort", "unit": "frames/s"}
+    for fif, key in ((0, "value"), (1, "one_frame_in_flight")):
+        if fif:
+            o.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, fif)
+        for k in range(0, 64, 1 if not fif else 64):  # capacity of every member of the ring for the whole orbit
+            o.render_uniforms(uniforms[k])
+            o.wait()
+        n = max(10, min(args.steps, 60))
+        for k in range(5):
+            o.render_uniforms(uniforms[k])
+        o.wait()
+        t0 = time.perf_counter()
+        for k in range(n):
+            o.render_uniforms(uniforms[(args.warmup + k) % 64])
+        o.wait()
+        dt = time.perf_counter() - t0
+        out[key] = n / dt
+        out["ms_per_step" if not fif else "one_frame_ms_per_step"] = dt / n * 1e3
+        out["steps"] = n
+    st = o.stats()
+    out.update(intersections=st["num_intersections"], sort_passes=st["sort_passes"], frames_in_flight=3)
+    o.destroy()
+    return out
 
 
 def copy_probe(dev, nbytes=512 << 20, iters=10):
@@ -524,8 +567,16 @@ def main():
             ab = algorithmic_bytes(st, W, H, T)
             stages = {}
             for name, us in st["stage_us_mean"].items():
-                gbs = ab[name] / (us * 1e-6) / 1e9 if us > 0 else 0.0
-                stages[name] = {"us": round(us, 2), "alg_bytes": int(ab[name]), "GBps": round(gbs, 1),
+                if name == "ranges" and st.get("tight_binning"):
+                    # the tight row pipeline has no ranges kernel (they fall out of the expansion's scan): SURVEY's bytes of the stage
+                    # are priced together with "sort", over the time of both brackets
+                    stages[name] = {"us": round(us, 2), "alg_bytes": int(ab[name]), "GBps": None, "hbm_frac": None, "priced_with": "sort"}
+                    continue
+                a_, u_ = ab[name], us
+                if name == "sort" and st.get("tight_binning"):
+                    a_, u_ = ab["sort"] + ab["ranges"], us + st["stage_us_mean"]["ranges"]
+                gbs = a_ / (u_ * 1e-6) / 1e9 if u_ > 0 else 0.0
+                stages[name] = {"us": round(us, 2), "alg_bytes": int(a_), "GBps": round(gbs, 1),
                                 "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
             dom = max(st["stage_us_mean"], key=lambda k_: st["stage_us_mean"][k_])
             dus = st["stage_us_mean"][dom]
@@ -558,16 +609,7 @@ def main():
             line["invalid_reason"] = trouble.get("truncated", "truncated frames")
         if not multi and not args.no_verify:
             line.update(self_check(gsplat, _abi, r, W, H, ts, local_rank, uniforms[(args.warmup + args.steps - 1) % 64], args))
-            rb = _KEEP.get("reference_binning")
-            if rb and "roofline" in line and line["roofline"]["kernel"] == "blend" and line["config"]["tight_binning"]:
-                # SURVEY 8(d)'s figure for the blend is 40 B per staged entry of the REFERENCE's lists; the tight binning of the product
-                # path removes the entries the reference would stage and skip, so `achieved` (the bytes of the lists this build really
-                # walks) fell although the kernel got faster.  The same launch time against the reference's lists for the last camera:
-                ref_bytes = 40 * rb["processed"] + 4 * W * H
-                ach = ref_bytes / (line["roofline"]["launch_us"] * 1e-6) / 1e9
-                line["roofline"]["reference_equivalent"] = {"alg_bytes": int(ref_bytes), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                                                            "staged_entries_reference_binning": rb["processed"], "intersections_reference_binning": rb["intersections"],
-                                                            "note": "SURVEY 8(d) bytes of the reference's lists for the last camera / this build's launch time"}
+            line["reference_binning"] = reference_binning_leg(gsplat, _abi, r, W, H, ts, local_rank, uniforms, args, eflag)
         if not multi and not args.no_cpu:
             u_last = uniforms[(args.warmup + args.steps - 1) % 64]
             line["cpu_baseline"], ref = cpu_baseline(host_scene, N, W, H, ts, u_last, args.cpu_max)

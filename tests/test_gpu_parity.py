@@ -57,6 +57,57 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
+def test_fused_blend_splat_centres_on_pixel_centres(oracle):
+    """The fused blend's loop drops the reference's `power <= 0` test (compute_tiles.wgsl:61) for batches whose conics are all
+    positive definite: there the power can only exceed 0 by rounding, which happens where dx, dy are (almost) 0.  This scene puts
+    4096 splat centres within ~1e-5 pixel of pixel centres (identity view / projection, dyadic positions), with strongly
+    correlated, anisotropic conics and high opacities: the pixel under a centre sees power = -0 .. -1e-9.  The fused image must
+    agree with the oracle within 1e-4 off the oracle's ill-conditioned pixels, in both binnings, and the EXACT one bit for bit."""
+    from gsplat import _abi
+    W = H = 256
+    ts = 16
+    rng = np.random.Generator(np.random.Philox(key=[77, 1]))
+    g = 64
+    s = np.zeros((g * g, 80), dtype=np.float32)
+    kx, ky = np.meshgrid(np.arange(g), np.arange(g))
+    px = (kx.ravel() * 3 + 32).astype(np.float32)  # pixel centres 32, 35, ... (integer pixel coordinates ARE the centres: compute_tiles.wgsl:40)
+    py = (ky.ravel() * 3 + 32).astype(np.float32)
+    s[:, 0] = 2.0 * px / W - 1.0  # ndc = pos / (1 + 1e-7): uv * W lands within ~1e-5 of the integer
+    s[:, 1] = 2.0 * py / H - 1.0
+    s[:, 2] = 1.0
+    s[:, 4:7] = np.log(rng.uniform(0.004, 0.03, (g * g, 3))).astype(np.float32)  # 0.5 .. 4 pixels at focal 128, anisotropic
+    s[:, 8:12] = rng.standard_normal((g * g, 4)).astype(np.float32)
+    s[:, 12] = rng.uniform(1.0, 6.0, g * g).astype(np.float32)  # opacity 0.73 .. 0.998 (the 0.99 clamp included)
+    s[:, 16:19] = rng.uniform(0.5, 2.0, (g * g, 3)).astype(np.float32)
+    u = np.zeros(40, dtype=np.float32)
+    u[0] = u[5] = u[10] = u[15] = 1.0       # view = I (column-major)
+    u[16] = u[21] = u[26] = u[31] = 1.0     # proj = I: hom = (x, y, z, 1)
+    u[35] = u[36] = 0.5                     # tan_fov
+    u[37] = u[38] = 128.0                   # focal
+    u[39] = 1.0
+    ref = oracle.render(s, u, W, H, ts, want_illcond=True)
+    uvw = ref["gdata"].view(np.float32).reshape(-1, 16)[:, 0] * np.float32(W)
+    vis = ref["tile_counts"] > 0
+    assert vis.sum() > 3500 and np.abs(uvw[vis] - np.round(uvw[vis])).max() < 1e-3  # the centres really sit on pixel centres
+    from gpu_checks import check_image
+    for flags, exact in ((_abi.GS_FLAG_EXACT_BLEND, True), (0, False)):
+        r = _mk(s, W, H, ts, flags=flags)
+        for debug in (True, False):  # the reference's binning, then the tight row pipeline
+            r.render_uniforms(u, debug=debug)
+            r.wait()
+            if debug:
+                _check_stages(r, ref, exact_image=True) if exact else None
+            else:
+                check_product_lists(r, ref, oracle, W, H, ts)
+            rep = {}
+            # the oracle flags every pixel whose power is EXACTLY 0 (half of the centres here) as ill-conditioned; no decision
+            # actually flips on this scene, so the whole frame -- flagged pixels included -- is held to 1e-4
+            check_image(r, ref, exact, max_ill=0.1, report=None if exact else rep)
+            if not exact:
+                assert rep["max_err"] <= 1e-4 and rep["rgba8_max_lsb"] <= 1, rep
+        r.destroy()
+
+
 @pytest.mark.parametrize("variant", [0, 8, 16, 5 * 256])  # GS_OPT_BLEND_ABLATION: 0 = default (8x8-block waves), 8 = 4-wave workgroup per tile, 16 = whole-tile wave, 5<<8 = strip width 5
 @pytest.mark.parametrize("exact", [True, False])
 def test_blend_kernel_variants(oracle, variant, exact):
