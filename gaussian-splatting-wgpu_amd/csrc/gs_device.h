@@ -67,6 +67,12 @@ struct GsScene {
                        // both (round 2: 1.19 GB of traffic for 0.78 GB of algorithmic bytes, profiles/README.md)
 };
 
+struct GsPlyTable { // where the 11 + 48 values of a packed record live in a raw .ply vertex (gs_upload_ply)
+    uint32_t stride, nsrc, all_float;
+    uint16_t soff[11 + 48];
+    uint8_t stype[11 + 48], slot[11 + 48];
+};
+
 struct GsUniforms { // 160 B, renderer.ts:15-24
     float view[16];
     float proj[16];

@@ -3,6 +3,7 @@
 #include "gs_device.h"
 
 void gs_launch_repack(const void* d_aos, uint32_t n, const GsScene& s, hipStream_t st);
+void gs_launch_ply_chunk(const void* d_raw, uint32_t m, uint32_t first, const GsPlyTable& t, const GsScene& s, hipStream_t st);
 struct GsPreprocessLaunch { // the projection's launch as data (its uniforms are the only kernel arguments that change per frame)
     const void* func;
     uint32_t blocks;

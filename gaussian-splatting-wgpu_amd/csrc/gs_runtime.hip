@@ -97,6 +97,7 @@ struct gs_ctx {
     uint32_t blend_prof_blocks = 0;
     // scene planes
     void* scene_mem = nullptr;
+    size_t scene_bytes = 0;
     GsScene scene{};
     uint32_t n = 0;
     // per-gaussian frame buffers
@@ -349,19 +350,27 @@ static int32_t alloc_per_gaussian(gs_ctx* c, uint64_t n, uint64_t min_capacity =
     return alloc_kv(c, cap, rows);
 }
 
-static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
+// Frees the previous scene, allocates the per-gaussian work arrays and the resident scene arrays for n gaussians.
+static int32_t scene_alloc(gs_ctx* c, uint64_t n) {
     int32_t rc = alloc_per_gaussian(c, n);
     if (rc != GS_OK) return rc;
     const size_t np = ((size_t)n + 63) & ~(size_t)63; // plane stride keeps every plane and both record arrays 256-byte aligned
     const size_t bytes = np * 4 * 4 + np * 32 + (size_t)n * 192;
     HIP_TRY(hipMalloc(&c->scene_mem, std::max<size_t>(bytes, 256)));
+    c->scene_bytes = bytes;
     char* p = (char*)c->scene_mem;
     GsScene& s = c->scene;
     s.px = (float*)p; p += np * 4; s.py = (float*)p; p += np * 4; s.pz = (float*)p; p += np * 4;
     s.smax = (float*)p; p += np * 4;
     s.geo = (float4*)p; p += np * 32;
     s.sh = (float4*)p;
-    if (n) gs_launch_repack(d_aos, (uint32_t)n, s, c->stream);
+    return GS_OK;
+}
+
+static int32_t upload_common(gs_ctx* c, const void* d_aos, uint64_t n) {
+    int32_t rc = scene_alloc(c, n);
+    if (rc != GS_OK) return rc;
+    if (n) gs_launch_repack(d_aos, (uint32_t)n, c->scene, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GS_OK;
@@ -390,6 +399,7 @@ GS_EXPORT int32_t gs_share_splats(gs_ctx* c, gs_ctx* owner) {
     int32_t rc = alloc_per_gaussian(c, owner->n, c->cfg.max_intersections ? 0 : owner->capacity, owner->row_cap);
     if (rc != GS_OK) return rc;
     c->scene_mem = owner->scene_mem; // read-only during a frame; the owner must outlive this context
+    c->scene_bytes = owner->scene_bytes;
     c->scene = owner->scene;
     c->scene_borrowed = true;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -768,6 +778,8 @@ static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
     case GS_BUF_BLOCK_MASKS: *ptr = c->valsS; *bytes = I * 4; return GS_OK; // tight frames: id | mask << 28 (gs_read_buffer separates them)
     case GS_BUF_RANGES: *ptr = c->ranges; *bytes = (uint64_t)c->T * 4; return GS_OK;
     case GS_BUF_RGBA8: *ptr = c->last_ext ? c->last_ext : (void*)c->rgba8; *bytes = px * 4; return GS_OK;
+    case 12: // TESTS ONLY: the resident scene arrays as one block (position planes, largest log-scale, geometry, SH records)
+        *ptr = c->scene_mem; *bytes = c->scene_bytes; return GS_OK;
     case 11: // PROFILING ONLY: per-walker stamps of the blend (GS_OPT_BLEND_ABLATION bit 16)
         if (!c->blend_prof) return fail(GS_ERR_INVALID_ARGUMENT, "no blend profile (GS_OPT_BLEND_ABLATION bit 16)");
         *ptr = c->blend_prof; *bytes = (uint64_t)c->blend_prof_blocks * 16; return GS_OK;
@@ -996,6 +1008,93 @@ GS_EXPORT int32_t gs_assemble_slabs(gs_ctx* c, const void* d_slabs, const uint32
 
 struct PlyProp { std::string name; int type; /* 0 other (0 bytes), 1 float, 2 uchar */ uint32_t offset; };
 
+// What decodeHeader (ply.ts:49-102) and PackedGaussians' constructor (:162-228) derive from the header: where the vertex data
+// starts, the vertex count and stride, and for each of the 11 + 3 (degree + 1)^2 values of a packed record its byte offset and
+// type in a vertex and its float slot in the 320-byte record (ply.ts:190-198).
+struct PlyLayout {
+    uint64_t data_off = 0, vertex_count = 0;
+    uint32_t stride = 0;
+    int degree = 0, nsrc = 0;
+    uint32_t soff[11 + 48], stype[11 + 48], slot[11 + 48];
+    bool all_float = true;
+};
+
+// header: the first bytes of the file (at least up to and including "end_header\n")
+static int32_t ply_parse_header(const unsigned char* buf, size_t len, PlyLayout& L) {
+    static const char kEnd[] = "end_header";
+    size_t hdr_end = std::string::npos;
+    for (size_t i = 0; i + sizeof(kEnd) - 1 <= len; ++i)
+        if (memcmp(buf + i, kEnd, sizeof(kEnd) - 1) == 0) { hdr_end = i; break; }
+    if (hdr_end == std::string::npos) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: no end_header");
+    const std::string header((const char*)buf, hdr_end + sizeof(kEnd) - 1);
+    L.data_off = hdr_end + sizeof(kEnd) - 1 + 1; // the byte after "end_header" (the newline), ply.ts:94
+    std::vector<PlyProp> props;
+    size_t pos = 0;
+    while (pos < header.size()) {
+        size_t eol = header.find('\n', pos);
+        if (eol == std::string::npos) eol = header.size();
+        std::string line = header.substr(pos, eol - pos);
+        pos = eol + 1;
+        size_t a = line.find_first_not_of(" \t\r"), b = line.find_last_not_of(" \t\r");
+        if (a == std::string::npos) continue;
+        line = line.substr(a, b - a + 1);
+        if (line.rfind("element vertex", 0) == 0) {
+            size_t d = line.find_first_of("0123456789");
+            if (d != std::string::npos) L.vertex_count = strtoull(line.c_str() + d, nullptr, 10);
+        } else if (line.rfind("property", 0) == 0) {
+            char w0[64], w1[64], w2[128];
+            if (sscanf(line.c_str(), "%63s %63s %127s", w0, w1, w2) == 3) {
+                int type = strcmp(w1, "float") == 0 ? 1 : strcmp(w1, "uchar") == 0 ? 2 : 0;
+                bool dup = false;
+                for (auto& p : props) if (p.name == w2) { p.type = type; dup = true; }
+                if (!dup) props.push_back({w2, type, 0});
+            }
+        } else if (line == "end_header") {
+            break;
+        }
+    }
+    uint32_t stride = 0, n_rest = 0;
+    for (auto& p : props) {
+        p.offset = stride;
+        stride += p.type == 1 ? 4u : p.type == 2 ? 1u : 0u;
+        if (p.name.rfind("f_rest_", 0) == 0) ++n_rest;
+    }
+    L.stride = stride;
+    const uint32_t per_color = n_rest / 3;
+    int degree = -1;
+    for (int d = 0; d <= 3; ++d) if ((uint32_t)((d + 1) * (d + 1) - 1) == per_color && n_rest % 3 == 0) degree = d;
+    if (degree < 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: Unsupported SH degree (%u f_rest properties)", n_rest); // ply.ts:136
+    L.degree = degree;
+    auto find = [&](const std::string& name) -> const PlyProp* {
+        for (auto& p : props) if (p.name == name) return &p;
+        return nullptr;
+    };
+    const char* base_names[11] = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "opacity"};
+    const int base_slot[11] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 11, 12};
+    L.nsrc = 0;
+    L.all_float = true;
+    auto add = [&](const PlyProp* p, int sl) {
+        L.soff[L.nsrc] = p->offset; L.stype[L.nsrc] = (uint32_t)p->type; L.slot[L.nsrc] = (uint32_t)sl; ++L.nsrc;
+        L.all_float = L.all_float && p->type == 1;
+    };
+    for (int i = 0; i < 11; ++i) {
+        const PlyProp* p = find(base_names[i]);
+        if (!p) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: missing property %s", base_names[i]);
+        add(p, base_slot[i]);
+    }
+    const int nsh = (degree + 1) * (degree + 1);
+    for (int k = 0; k < nsh; ++k)
+        for (int c = 0; c < 3; ++c) {
+            char nm[32];
+            if (k == 0) snprintf(nm, sizeof(nm), "f_dc_%d", c);
+            else snprintf(nm, sizeof(nm), "f_rest_%u", (unsigned)(c * per_color + (k - 1)));
+            const PlyProp* p = find(nm);
+            if (!p) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: missing property %s", nm);
+            add(p, 16 + 4 * k + c);
+        }
+    return GS_OK;
+}
+
 GS_EXPORT int32_t gs_ply_load(const char* path, void** records, uint64_t* n_out, int32_t* sh_degree) {
     if (!path || !records || !n_out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: null argument");
     *records = nullptr;
@@ -1016,93 +1115,28 @@ GS_EXPORT int32_t gs_ply_load(const char* path, void** records, uint64_t* n_out,
     if (!buf.p) { fclose(fp); return fail(GS_ERR_OUT_OF_MEMORY, "gs_ply_load: out of host memory"); }
     if (fsize > 0 && fread(buf.p, 1, (size_t)fsize, fp) != (size_t)fsize) { fclose(fp); return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: short read"); }
     fclose(fp);
-    static const char kEnd[] = "end_header";
-    size_t hdr_end = std::string::npos;
-    for (size_t i = 0; i + sizeof(kEnd) - 1 <= buf.size(); ++i)
-        if (memcmp(buf.data() + i, kEnd, sizeof(kEnd) - 1) == 0) { hdr_end = i; break; }
-    if (hdr_end == std::string::npos) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: no end_header");
-    const std::string header((const char*)buf.data(), hdr_end + sizeof(kEnd) - 1);
-    const size_t data_off = hdr_end + sizeof(kEnd) - 1 + 1; // the byte after "end_header" (the newline), ply.ts:94
-    uint64_t vertex_count = 0;
-    std::vector<PlyProp> props;
-    size_t pos = 0;
-    while (pos < header.size()) {
-        size_t eol = header.find('\n', pos);
-        if (eol == std::string::npos) eol = header.size();
-        std::string line = header.substr(pos, eol - pos);
-        pos = eol + 1;
-        size_t a = line.find_first_not_of(" \t\r"), b = line.find_last_not_of(" \t\r");
-        if (a == std::string::npos) continue;
-        line = line.substr(a, b - a + 1);
-        if (line.rfind("element vertex", 0) == 0) {
-            size_t d = line.find_first_of("0123456789");
-            if (d != std::string::npos) vertex_count = strtoull(line.c_str() + d, nullptr, 10);
-        } else if (line.rfind("property", 0) == 0) {
-            char w0[64], w1[64], w2[128];
-            if (sscanf(line.c_str(), "%63s %63s %127s", w0, w1, w2) == 3) {
-                int type = strcmp(w1, "float") == 0 ? 1 : strcmp(w1, "uchar") == 0 ? 2 : 0;
-                bool dup = false;
-                for (auto& p : props) if (p.name == w2) { p.type = type; dup = true; }
-                if (!dup) props.push_back({w2, type, 0});
-            }
-        } else if (line == "end_header") {
-            break;
-        }
-    }
-    uint32_t stride = 0, n_rest = 0;
-    for (auto& p : props) {
-        p.offset = stride;
-        stride += p.type == 1 ? 4u : p.type == 2 ? 1u : 0u;
-        if (p.name.rfind("f_rest_", 0) == 0) ++n_rest;
-    }
-    const uint32_t per_color = n_rest / 3;
-    int degree = -1;
-    for (int d = 0; d <= 3; ++d) if ((uint32_t)((d + 1) * (d + 1) - 1) == per_color && n_rest % 3 == 0) degree = d;
-    if (degree < 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: Unsupported SH degree (%u f_rest properties)", n_rest); // ply.ts:136
-    auto find = [&](const std::string& name) -> const PlyProp* {
-        for (auto& p : props) if (p.name == name) return &p;
-        return nullptr;
-    };
-    const char* base_names[11] = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "opacity"};
-    const int base_slot[11] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 11, 12};
-    const PlyProp* src[11 + 48];
-    int slot[11 + 48];
-    int nsrc = 0;
-    for (int i = 0; i < 11; ++i) {
-        const PlyProp* p = find(base_names[i]);
-        if (!p) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: missing property %s", base_names[i]);
-        src[nsrc] = p; slot[nsrc++] = base_slot[i];
-    }
-    const int nsh = (degree + 1) * (degree + 1);
-    for (int k = 0; k < nsh; ++k)
-        for (int c = 0; c < 3; ++c) {
-            char nm[32];
-            if (k == 0) snprintf(nm, sizeof(nm), "f_dc_%d", c);
-            else snprintf(nm, sizeof(nm), "f_rest_%u", (unsigned)(c * per_color + (k - 1)));
-            const PlyProp* p = find(nm);
-            if (!p) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: missing property %s", nm);
-            src[nsrc] = p; slot[nsrc++] = 16 + 4 * k + c;
-        }
-    if (buf.size() < data_off + vertex_count * (uint64_t)stride) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: vertex data truncated");
+    PlyLayout L;
+    int32_t rc = ply_parse_header(buf.data(), buf.size(), L);
+    if (rc != GS_OK) return rc;
+    const uint64_t vertex_count = L.vertex_count;
+    const uint32_t stride = L.stride;
+    if (buf.size() < L.data_off + vertex_count * (uint64_t)stride) return fail(GS_ERR_INVALID_ARGUMENT, "gs_ply_load: vertex data truncated");
     float* out = (float*)calloc((size_t)std::max<uint64_t>(vertex_count, 1) * 80, sizeof(float));
     if (!out) return fail(GS_ERR_OUT_OF_MEMORY, "gs_ply_load: out of host memory");
-    // flat (source offset, type, destination slot) table; vertices are independent, so the pass is split over threads
-    uint32_t soff[11 + 48], stype[11 + 48];
-    bool all_float = true;
-    for (int s2 = 0; s2 < nsrc; ++s2) { soff[s2] = src[s2]->offset; stype[s2] = (uint32_t)src[s2]->type; all_float = all_float && src[s2]->type == 1; }
-    const unsigned char* vbase = buf.data() + data_off;
+    // vertices are independent, so the pass is split over threads
+    const unsigned char* vbase = buf.data() + L.data_off;
     auto work = [&](uint64_t i0, uint64_t i1) {
         for (uint64_t i = i0; i < i1; ++i) {
             const unsigned char* v = vbase + i * stride;
             float* rec = out + i * 80;
-            if (all_float) {
-                for (int s2 = 0; s2 < nsrc; ++s2) memcpy(&rec[slot[s2]], v + soff[s2], 4);
+            if (L.all_float) {
+                for (int s2 = 0; s2 < L.nsrc; ++s2) memcpy(&rec[L.slot[s2]], v + L.soff[s2], 4);
             } else {
-                for (int s2 = 0; s2 < nsrc; ++s2) {
+                for (int s2 = 0; s2 < L.nsrc; ++s2) {
                     float f = 0.0f; // a property of another type reads as `undefined` in the reference; 0 here
-                    if (stype[s2] == 1) memcpy(&f, v + soff[s2], 4);
-                    else if (stype[s2] == 2) f = (float)((double)v[soff[s2]] / 255.0);
-                    rec[slot[s2]] = f;
+                    if (L.stype[s2] == 1) memcpy(&f, v + L.soff[s2], 4);
+                    else if (L.stype[s2] == 2) f = (float)((double)v[L.soff[s2]] / 255.0);
+                    rec[L.slot[s2]] = f;
                 }
             }
         }
@@ -1116,21 +1150,81 @@ GS_EXPORT int32_t gs_ply_load(const char* path, void** records, uint64_t* n_out,
     for (auto& th : pool) th.join();
     *records = out;
     *n_out = vertex_count;
-    if (sh_degree) *sh_degree = degree;
+    if (sh_degree) *sh_degree = L.degree;
     return GS_OK;
 }
 
 GS_EXPORT void gs_ply_free(void* records) { free(records); }
 
+static int32_t scene_alloc(gs_ctx* c, uint64_t n);
+// Streams a .ply straight into the resident scene arrays: the file is read in chunks of 64 Ki vertices into one of
+// two pinned staging buffers, copied to the device and converted THERE into the final layout (position planes, geometry and SH
+// records: gs_ply_chunk_kernel) while the next chunk is being read.  No N x 320-byte array exists on either side: peak host
+// memory is the two staging buffers (2 x 64 Ki x vertex stride, ~32 MB), whatever the size of the scene.  The reference builds
+// the whole packed buffer in JS first (ply.ts:204-228: "seconds to a couple of minutes", index.html:16).
 GS_EXPORT int32_t gs_upload_ply(gs_ctx* c, const char* path, uint64_t* n_out) {
-    void* rec = nullptr;
-    uint64_t n = 0;
-    int32_t rc = gs_ply_load(path, &rec, &n, nullptr);
-    if (rc != GS_OK) return rc;
-    rc = gs_upload_splats(c, rec, n);
-    free(rec);
-    if (rc == GS_OK && n_out) *n_out = n;
-    return rc;
+    if (!c || !path) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_ply: null argument");
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_ply: cannot open %s", path);
+    std::vector<unsigned char> head(1 << 16);
+    const size_t got = fread(head.data(), 1, head.size(), fp);
+    PlyLayout L;
+    int32_t rc = ply_parse_header(head.data(), got, L);
+    if (rc != GS_OK) { fclose(fp); return rc; }
+    fseek(fp, 0, SEEK_END);
+    const uint64_t fsize = (uint64_t)ftell(fp);
+    const uint64_t n = L.vertex_count;
+    if (n >= (1ull << 31)) { fclose(fp); return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_ply: too many gaussians"); }
+    if (fsize < L.data_off + n * (uint64_t)L.stride) { fclose(fp); return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_ply: vertex data truncated"); }
+    hipError_t he = hipSetDevice(c->cfg.device);
+    if (he != hipSuccess) { fclose(fp); return fail(GS_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
+    drop_shadows(c);
+    rc = scene_alloc(c, n);
+    if (rc != GS_OK) { fclose(fp); return rc; }
+    if (L.degree < 3 && n) { // coefficients the file does not have stay 0 (the shader hard-codes 16: process_gaussians.wgsl:6)
+        hipError_t e0 = hipMemsetAsync((void*)c->scene.sh, 0, (size_t)n * 192, c->stream);
+        if (e0 != hipSuccess) { fclose(fp); return fail(GS_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e0)); }
+    }
+    const uint64_t CH = 65536;
+    const size_t chunk_bytes = (size_t)CH * L.stride;
+    unsigned char* h_stage[2] = {nullptr, nullptr};
+    unsigned char* d_stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int k = 0; k < 2; ++k) {
+            if (h_stage[k]) hipHostFree(h_stage[k]);
+            if (d_stage[k]) hipFree(d_stage[k]);
+            if (done[k]) hipEventDestroy(done[k]);
+        }
+        fclose(fp);
+    };
+#define PLY_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    for (int k = 0; k < 2; ++k) {
+        PLY_TRY(hipHostMalloc((void**)&h_stage[k], std::max<size_t>(chunk_bytes, 256), hipHostMallocDefault));
+        PLY_TRY(hipMalloc((void**)&d_stage[k], std::max<size_t>(chunk_bytes, 256)));
+        PLY_TRY(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+    }
+    GsPlyTable tab;
+    tab.stride = L.stride; tab.nsrc = (uint32_t)L.nsrc; tab.all_float = L.all_float ? 1u : 0u;
+    for (int k = 0; k < L.nsrc; ++k) { tab.soff[k] = (uint16_t)L.soff[k]; tab.stype[k] = (uint8_t)L.stype[k]; tab.slot[k] = (uint8_t)L.slot[k]; }
+    if (L.stride > 0xFFFFu) { cleanup(); return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_ply: vertex stride %u too large", L.stride); }
+    fseek(fp, (long)L.data_off, SEEK_SET);
+    uint32_t it = 0;
+    for (uint64_t v0 = 0; v0 < n; v0 += CH, ++it) {
+        const int k = (int)(it & 1u);
+        const uint64_t m = std::min<uint64_t>(CH, n - v0);
+        if (it >= 2) PLY_TRY(hipEventSynchronize(done[k])); // the copy out of this staging buffer two chunks ago has finished
+        if (fread(h_stage[k], 1, (size_t)(m * L.stride), fp) != (size_t)(m * L.stride)) { cleanup(); return fail(GS_ERR_INVALID_ARGUMENT, "gs_upload_ply: short read"); }
+        PLY_TRY(hipMemcpyAsync(d_stage[k], h_stage[k], (size_t)(m * L.stride), hipMemcpyHostToDevice, c->stream));
+        gs_launch_ply_chunk(d_stage[k], (uint32_t)m, (uint32_t)v0, tab, c->scene, c->stream);
+        PLY_TRY(hipEventRecord(done[k], c->stream));
+    }
+    PLY_TRY(hipGetLastError());
+    PLY_TRY(hipStreamSynchronize(c->stream));
+#undef PLY_TRY
+    cleanup();
+    if (n_out) *n_out = n;
+    return GS_OK;
 }
 
 // ---- stand-alone stages ---------------------------------------------------------------------------------

@@ -46,6 +46,50 @@ __global__ __launch_bounds__(256) void gs_repack_kernel(const float4* __restrict
     }
 }
 
+// ---- upload from a .ply, chunk by chunk: raw vertices (any property order, float / uchar) -> the same arrays ----------
+// One thread per (vertex, value): the 11 + 48 values PackedGaussians reads from a vertex (ply.ts:166-198).  uchar values are
+// value / 255 evaluated in double and rounded to f32, as the reference's Number arithmetic does (ply.ts:113-119).
+__global__ __launch_bounds__(256) void gs_ply_chunk_kernel(const unsigned char* __restrict__ raw, uint32_t m, uint32_t first, GsPlyTable t,
+                                                            float* px, float* py, float* pz, float* smax, float* geo, float* sh) {
+    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (uint64_t)m * t.nsrc) return;
+    const uint32_t v = (uint32_t)(id / t.nsrc), k = (uint32_t)(id % t.nsrc);
+    const unsigned char* src = raw + (uint64_t)v * t.stride;
+    auto rd = [&](uint32_t kk) {
+        const unsigned char* q = src + t.soff[kk];
+        if (t.stype[kk] == 1u) {
+            uint32_t w;
+            if (t.all_float) w = *reinterpret_cast<const uint32_t*>(q); // every property is 4 bytes: aligned
+            else w = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            return __uint_as_float(w);
+        }
+        if (t.stype[kk] == 2u) return (float)((double)q[0] / 255.0);
+        return 0.0f;
+    };
+    const uint64_t g = (uint64_t)first + v;
+    const uint32_t slot = t.slot[k];
+    const float val = rd(k);
+    if (slot == 0u) px[g] = val;
+    else if (slot == 1u) py[g] = val;
+    else if (slot == 2u) pz[g] = val;
+    else if (slot >= 4u && slot <= 6u) {
+        geo[g * 8 + (slot - 4u)] = val;
+        if (slot == 4u) smax[g] = __builtin_fmaxf(val, __builtin_fmaxf(rd(4), rd(5))); // table entries 3, 4, 5 are scale_0..2
+    } else if (slot >= 8u && slot <= 11u) geo[g * 8 + 4u + (slot - 8u)] = val;
+    else if (slot == 12u) geo[g * 8 + 3u] = val;
+    else { // SH coefficient kk, channel c at record float 16 + 4 kk + c -> packed float 3 kk + c
+        const uint32_t kk = (slot - 16u) >> 2, ch = (slot - 16u) & 3u;
+        sh[g * 48 + 3u * kk + ch] = val;
+    }
+}
+// a degree below 3 leaves the higher coefficients of the (pre-zeroed) SH array at 0: the shader hard-codes 16 (process_gaussians.wgsl:6)
+void gs_launch_ply_chunk(const void* d_raw, uint32_t m, uint32_t first, const GsPlyTable& t, const GsScene& s, hipStream_t st) {
+    const uint64_t total = (uint64_t)m * t.nsrc;
+    if (!total) return;
+    hipLaunchKernelGGL(gs_ply_chunk_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, (const unsigned char*)d_raw, m, first, t,
+                       (float*)s.px, (float*)s.py, (float*)s.pz, (float*)s.smax, (float*)s.geo, (float*)s.sh);
+}
+
 // ---- canonical 3x3 helpers: column-major m[c][r]; (A*B)[c][r] = sum_k A[k][r]*B[c][k], k ascending
 struct M3 { float m[3][3]; };
 __device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {

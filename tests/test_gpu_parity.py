@@ -536,11 +536,64 @@ def test_ply_file_to_frame(tmp_path, oracle):
     assert pg.numGaussians == n and pg.sphericalHarmonicsDegree == 3
     np.testing.assert_array_equal(np.asarray(pg.gaussiansBuffer).view(np.uint32), s.view(np.uint32))
     r = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, 16, flags=_abi.GS_FLAG_EXACT_BLEND | _abi.GS_FLAG_F32_TAP)
-    # replace the scene through the one-call path as well
+    r.render_uniforms(u)
+    r.wait()
+    scene_from_records = r.read_buffer(12)  # (tests only) the resident scene arrays, as gs_upload_splats laid them out
+    # replace the scene through the streaming path: file -> pinned chunks -> device arrays, no 320-byte records anywhere
     cnt = ctypes.c_uint64()
     _abi.check(_abi.load().gs_upload_ply(r._ctx, path.encode(), ctypes.byref(cnt)))
     assert cnt.value == n
     r.render_uniforms(u, debug=True)
     r.wait()
+    np.testing.assert_array_equal(r.read_buffer(12), scene_from_records)  # byte-identical device scene
+    _check_stages(r, ref, exact_image=True)
+    r.destroy()
+
+
+def test_ply_streaming_chunks_uchar_and_low_degree(tmp_path, oracle):
+    """gs_upload_ply beyond one 64 Ki-vertex chunk (three chunks), with a property order of its own, a property the packer does not
+    use (nx), a uchar property (value / 255, ply.ts:113-119: vertices of 93 bytes, so the floats of most vertices are unaligned)
+    and SH degree 1 (zero-padded to the 16 coefficients the shader reads)."""
+    import ctypes
+    import gsplat
+    from gsplat import _abi
+    n, W, H = 150_000, 320, 192
+    rec = scene(n).copy()
+    rec[:, 16 + 4 * 4:16 + 4 * 16] = 0.0  # degree 1: coefficients 4..15 absent
+    op_u8 = np.clip(np.round(127.5 + 20.0 * rec[:, 12]), 0, 255).astype(np.uint8)
+    rec[:, 12] = (op_u8.astype(np.float64) / 255.0).astype(np.float32)  # the opacity logit travels as a uchar
+    names = ["rot_0", "rot_1", "rot_2", "rot_3", "x", "y", "z", "nx", "scale_0", "scale_1", "scale_2", "f_dc_0", "f_dc_1", "f_dc_2"] + \
+            ["f_rest_%d" % i for i in range(9)]
+    cols = {"rot_0": rec[:, 8], "rot_1": rec[:, 9], "rot_2": rec[:, 10], "rot_3": rec[:, 11], "x": rec[:, 0], "y": rec[:, 1], "z": rec[:, 2],
+            "nx": 0 * rec[:, 0], "scale_0": rec[:, 4], "scale_1": rec[:, 5], "scale_2": rec[:, 6]}
+    for c in range(3):
+        cols["f_dc_%d" % c] = rec[:, 16 + c]
+        for i in range(3):
+            cols["f_rest_%d" % (c * 3 + i)] = rec[:, 16 + 4 * (i + 1) + c]
+    dt = np.dtype([(k, "<f4") for k in names] + [("opacity", "u1")], align=False)  # 93-byte vertices: floats at odd offsets
+    arr = np.zeros(n, dtype=dt)
+    for k in names:
+        arr[k] = cols[k]
+    arr["opacity"] = op_u8
+    path = str(tmp_path / "odd.ply")
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n + "".join("property float %s\n" % k for k in names) +
+                 "property uchar opacity\nend_header\n").encode())
+        f.write(arr.tobytes())
+    u = _uniforms(W, H, step=21)
+    ref = oracle.render(rec, u, W, H, 16)
+    pg = gsplat.PackedGaussians.from_ply(path)  # gs_ply_load: the packed 320-byte records
+    assert pg.numGaussians == n and pg.sphericalHarmonicsDegree == 1
+    np.testing.assert_array_equal(np.asarray(pg.gaussiansBuffer).view(np.uint32), rec.view(np.uint32))
+    r = gsplat.Renderer(gsplat.Canvas(W, H), None, 0, pg, 16, flags=_abi.GS_FLAG_EXACT_BLEND | _abi.GS_FLAG_F32_TAP)
+    r.render_uniforms(u)
+    r.wait()
+    want = r.read_buffer(12)
+    cnt = ctypes.c_uint64()
+    _abi.check(_abi.load().gs_upload_ply(r._ctx, path.encode(), ctypes.byref(cnt)))
+    assert cnt.value == n
+    r.render_uniforms(u, debug=True)
+    r.wait()
+    np.testing.assert_array_equal(r.read_buffer(12), want)
     _check_stages(r, ref, exact_image=True)
     r.destroy()
