@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -89,6 +90,11 @@ struct gs_ctx {
     gs_ctx* last = nullptr;                   // who rendered the last frame (this or a shadow); nullptr = this
     uint32_t rr = 0;                          // next slot of the ring {this, shadows...}
     uint64_t cap_hint = 0, row_hint = 0;      // largest capacities any member of the ring has grown to
+    // gs_render_host / gs_wait_ticket (root ctx): the event of the last frame + copy of every ring member, who rendered which ticket
+    hipEvent_t ev_done = nullptr;
+    uint64_t next_ticket = 1;
+    struct { uint64_t ticket; gs_ctx* member; } tickets[64] = {};
+    std::mutex ticket_mu;
     bool tile_cull = true;                    // GS_OPT_TILE_CULL: tight (opacity-aware) binning in gs_render / gs_render_to
     bool last_tight = false;                  // the last frame used it
     uint32_t grid_persist = 0; // workgroups of the persistent (ticket-loop) kernels
@@ -313,6 +319,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     if (c->have_events)
         for (auto& row : c->ev)
             for (auto& e : row) hipEventDestroy(e);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return GS_OK;
@@ -729,6 +736,47 @@ GS_EXPORT int32_t gs_render(gs_ctx* c, const void* uniforms) {
     if (rc == GS_OK) c->last = t;
     return rc;
 }
+GS_EXPORT int32_t gs_render_host(gs_ctx* c, const void* uniforms, void* host_dst, uint64_t size, uint64_t* ticket) {
+    if (!c || !uniforms || !host_dst || !ticket) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render_host: null argument");
+    const uint64_t bytes = (uint64_t)c->frame.slab_w * c->frame.height * 4;
+    if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_render_host: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
+    int32_t rc = gs_render(c, uniforms);
+    if (rc != GS_OK) return rc;
+    gs_ctx* t = last_of(c);
+    if (!t->ev_done) HIP_TRY(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(host_dst, t->rgba8, bytes, hipMemcpyDeviceToHost, t->stream));
+    std::lock_guard<std::mutex> lk(c->ticket_mu);
+    HIP_TRY(hipEventRecord(t->ev_done, t->stream));
+    const uint64_t k = c->next_ticket++;
+    c->tickets[k & 63u].ticket = k;
+    c->tickets[k & 63u].member = t;
+    *ticket = k;
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_wait_ticket(gs_ctx* c, uint64_t ticket) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "gs_wait_ticket: null ctx");
+    gs_ctx* t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->ticket_mu);
+        if (ticket == 0 || ticket >= c->next_ticket) return fail(GS_ERR_INVALID_ARGUMENT, "gs_wait_ticket: unknown ticket %llu", (unsigned long long)ticket);
+        if (c->next_ticket - ticket > 64 || c->tickets[ticket & 63u].ticket != ticket) return GS_OK; // retired long ago: its member has rendered later frames since
+        t = c->tickets[ticket & 63u].member;
+    }
+    // the member's event is re-recorded by every later frame it renders: waiting on it is waiting for at least this ticket's frame
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventSynchronize(t->ev_done));
+    return GS_OK;
+}
+
+GS_EXPORT int32_t gs_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, "gs_host_alloc: null argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, std::max<size_t>((size_t)bytes, 256), hipHostMallocDefault));
+    return GS_OK;
+}
+GS_EXPORT void gs_host_free(void* p) { if (p) hipHostFree(p); }
+
 GS_EXPORT int32_t gs_render_debug(gs_ctx* c, const void* uniforms) {
     const int32_t rc = render_common(c, uniforms, true, nullptr);
     if (rc == GS_OK && c) c->last = c;

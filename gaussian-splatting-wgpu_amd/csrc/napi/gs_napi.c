@@ -57,6 +57,7 @@ static int get_u32_prop(napi_env env, napi_value obj, const char* name, uint32_t
 typedef struct {
     gs_ctx* ctx;
     int busy;            /* a renderAsync job owns the context */
+    int inflight;        /* renderToSink frames whose tickets are being waited for on workers (they only call gs_wait_ticket) */
     int destroy_pending; /* destroy() was called meanwhile */
 } ctx_box;
 
@@ -76,8 +77,8 @@ static gs_ctx* unwrap(napi_env env, napi_value v) {
         napi_throw_error(env, NULL, "gsplat: the context has been destroyed");
         return NULL;
     }
-    if (b->busy) {
-        napi_throw_error(env, NULL, "gsplat: a frame is in flight on this context (await renderAsync first)");
+    if (b->busy || b->inflight) {
+        napi_throw_error(env, NULL, "gsplat: a frame is in flight on this context (await renderAsync / the renderToSink promises first)");
         return NULL;
     }
     return b->ctx;
@@ -86,7 +87,7 @@ static gs_ctx* unwrap(napi_env env, napi_value v) {
 static void finalize_ctx(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
     ctx_box* box = (ctx_box*)data;
-    if (box->busy) { box->destroy_pending = 2; return; } /* the job frees the box when it completes */
+    if (box->busy || box->inflight) { box->destroy_pending = 2; return; } /* the last job frees the box when it completes */
     if (box->ctx) gs_destroy(box->ctx);
     free(box);
 }
@@ -151,7 +152,7 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
     void* p = NULL;
     if (argc < 1 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p) return NULL;
     ctx_box* box = (ctx_box*)p;
-    if (box->busy) { /* a frame is in flight on a worker: destroy when it completes */
+    if (box->busy || box->inflight) { /* a frame is in flight on a worker: destroy when it completes */
         if (!box->destroy_pending) box->destroy_pending = 1;
         return NULL;
     }
@@ -423,12 +424,147 @@ static napi_value js_load_ply(napi_env env, napi_callback_info info) {
     return o;
 }
 
+/* uploadPly(handle, path) -> n : the streaming loader (file -> pinned chunks -> device scene arrays, gs_upload_ply) */
+static napi_value js_upload_ply(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gs_ctx* ctx = argc >= 2 ? unwrap(env, argv[0]) : NULL;
+    if (!ctx) return NULL;
+    char path[4096];
+    size_t len = 0;
+    if (napi_get_value_string_utf8(env, argv[1], path, sizeof(path), &len) != napi_ok) {
+        napi_throw_type_error(env, NULL, "gsplat.uploadPly: path required");
+        return NULL;
+    }
+    uint64_t n = 0;
+    int32_t rc = gs_upload_ply(ctx, path, &n);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    napi_value v;
+    NAPI_CALL(env, napi_create_double(env, (double)n, &v));
+    return v;
+}
+
+/* hostAlloc(bytes) -> ArrayBuffer over page-locked memory (gs_host_alloc): a frame sink renderToSink copies into asynchronously */
+static void finalize_pinned(napi_env env, void* data, void* hint) { (void)env; (void)hint; gs_host_free(data); }
+static napi_value js_host_alloc(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    double bytes = 0;
+    if (argc < 1 || napi_get_value_double(env, argv[0], &bytes) != napi_ok || !(bytes > 0.0) || bytes > 17179869184.0) {
+        napi_throw_type_error(env, NULL, "gsplat.hostAlloc: byte count required");
+        return NULL;
+    }
+    void* p = NULL;
+    int32_t rc = gs_host_alloc((uint64_t)bytes, &p);
+    if (rc != GS_OK) return throw_gs(env, rc);
+    napi_value ab;
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, finalize_pinned, NULL, &ab) != napi_ok) {
+        gs_host_free(p);
+        napi_throw_error(env, NULL, "gsplat.hostAlloc: napi_create_external_arraybuffer failed");
+        return NULL;
+    }
+    return ab;
+}
+
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    ctx_box* box;
+    gs_ctx* ctx;
+    uint64_t ticket;
+    napi_ref sink_ref; /* keeps the sink alive until the copy has landed */
+    int32_t rc;
+    char err[512];
+} sink_job;
+
+static void sink_execute(napi_env env, void* data) {
+    (void)env;
+    sink_job* j = (sink_job*)data;
+    j->rc = gs_wait_ticket(j->ctx, j->ticket);
+    if (j->rc != GS_OK) { strncpy(j->err, gs_last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
+}
+
+static void sink_complete(napi_env env, napi_status status, void* data) {
+    sink_job* j = (sink_job*)data;
+    ctx_box* box = j->box;
+    napi_value v;
+    box->inflight--;
+    if (!box->inflight && !box->busy && box->destroy_pending) {
+        if (box->ctx) gs_destroy(box->ctx);
+        box->ctx = NULL;
+        if (box->destroy_pending == 2) free(box);
+        else box->destroy_pending = 0;
+    }
+    if (status == napi_ok && j->rc == GS_OK) {
+        napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg;
+        napi_create_string_utf8(env, j->rc != GS_OK ? j->err : "gsplat: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &v);
+        napi_reject_deferred(env, j->deferred, v);
+    }
+    napi_delete_reference(env, j->sink_ref);
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+/* renderToSink(handle, uniforms160, sink) -> Promise<void>: enqueues the frame and the copy of its pixels into `sink` NOW (on the
+ * calling thread, without waiting: gs_render_host) and resolves when both are complete (gs_wait_ticket on a libuv worker).
+ * Several may be outstanding: frame k+1 is enqueued while frame k is still being rendered and copied.  `sink`: ArrayBuffer or
+ * view of at least height * slabWidth * 4 bytes, ideally from hostAlloc(). */
+static napi_value js_render_to_sink(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    ctx_box* box = argc >= 3 ? unbox(env, argv[0]) : NULL;
+    if (!box) return NULL;
+    if (!box->ctx || box->busy || box->destroy_pending) {
+        napi_throw_error(env, NULL, "gsplat.renderToSink: the context is destroyed or owned by a renderAsync frame");
+        return NULL;
+    }
+    void *udata = NULL, *sink = NULL;
+    size_t ulen = 0, slen = 0;
+    if (!get_bytes(env, argv[1], &udata, &ulen) || ulen < GS_UNIFORM_BYTES || !get_bytes(env, argv[2], &sink, &slen)) {
+        napi_throw_type_error(env, NULL, "gsplat.renderToSink: need the 160-byte uniform block and a sink buffer");
+        return NULL;
+    }
+    sink_job* j = (sink_job*)calloc(1, sizeof(sink_job));
+    if (!j) { napi_throw_error(env, NULL, "gsplat.renderToSink: out of memory"); return NULL; }
+    j->box = box;
+    j->ctx = box->ctx;
+    int32_t rc = gs_render_host(box->ctx, udata, sink, (uint64_t)slen, &j->ticket);
+    if (rc != GS_OK) { free(j); return throw_gs(env, rc); }
+    napi_value promise, name;
+    if (napi_create_reference(env, argv[2], 1, &j->sink_ref) != napi_ok) {
+        gs_wait_ticket(box->ctx, j->ticket); /* the copy must not outlive the buffer */
+        free(j);
+        napi_throw_error(env, NULL, "gsplat.renderToSink: N-API call failed");
+        return NULL;
+    }
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "gsplat.sink", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, sink_execute, sink_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        gs_wait_ticket(box->ctx, j->ticket);
+        napi_delete_reference(env, j->sink_ref);
+        free(j);
+        napi_throw_error(env, NULL, "gsplat.renderToSink: N-API call failed");
+        return NULL;
+    }
+    box->inflight++;
+    return promise;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"create", js_create},       {"destroy", js_destroy},         {"uploadSplats", js_upload},
         {"renderSync", js_render_sync}, {"renderAsync", js_render_async}, {"readRgba8", js_read_rgba8},
         {"readBuffer", js_read_buffer}, {"stats", js_stats},             {"slab", js_slab},
-        {"loadPly", js_load_ply},    {"shareSplats", js_share},
+        {"loadPly", js_load_ply},    {"shareSplats", js_share},       {"uploadPly", js_upload_ply},
+        {"hostAlloc", js_host_alloc}, {"renderToSink", js_render_to_sink},
     };
     for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
         napi_value f;

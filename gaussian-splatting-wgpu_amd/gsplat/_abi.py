@@ -35,7 +35,7 @@ GS_OPT_PROJ_CHUNKS = 10
 ABI_SYMBOLS = ("gs_last_error", "gs_abi_version", "gs_create", "gs_destroy", "gs_upload_splats", "gs_upload_splats_device",
                "gs_share_splats",
                "gs_ply_load", "gs_ply_free", "gs_upload_ply",
-               "gs_render", "gs_render_debug", "gs_render_to", "gs_wait", "gs_read_rgba8", "gs_read_buffer", "gs_device_ptr",
+               "gs_render", "gs_render_debug", "gs_render_to", "gs_wait", "gs_render_host", "gs_wait_ticket", "gs_host_alloc", "gs_host_free", "gs_read_rgba8", "gs_read_buffer", "gs_device_ptr",
                "gs_get_stats", "gs_set_option", "gs_slab_width", "gs_assemble_slabs", "gs_sort_pairs_u32",
                "gs_exclusive_scan_u32")
 
@@ -90,6 +90,10 @@ def load():
     L.gs_render_debug.argtypes = [vp, vp]
     L.gs_render_to.argtypes = [vp, vp, vp]
     L.gs_wait.argtypes = [vp]
+    L.gs_render_host.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64)]
+    L.gs_wait_ticket.argtypes = [vp, u64]
+    L.gs_host_alloc.argtypes = [u64, ctypes.POINTER(vp)]
+    L.gs_host_free.argtypes = [vp]
     L.gs_read_rgba8.argtypes = [vp, vp, u64]
     L.gs_read_buffer.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64)]
     L.gs_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp)]
@@ -100,9 +104,10 @@ def load():
     L.gs_sort_pairs_u32.argtypes = [i32, vp, vp, u64, u32]
     L.gs_exclusive_scan_u32.argtypes = [i32, vp, u64, ctypes.POINTER(u64)]
     for name in ABI_SYMBOLS:
-        if name not in ("gs_last_error", "gs_ply_free"):
+        if name not in ("gs_last_error", "gs_ply_free", "gs_host_free"):
             getattr(L, name).restype = i32
     L.gs_ply_free.restype = None
+    L.gs_host_free.restype = None
     _lib = L
     return L
 

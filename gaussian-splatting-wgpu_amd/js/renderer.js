@@ -42,8 +42,22 @@ class Renderer {
     if (!canvas || !(canvas.width > 0) || !(canvas.height > 0)) throw new Error('WebGPU context not found!'); // renderer.ts:108-111
     this.handle = n.create({ width: canvas.width, height: canvas.height, tileSize, device: ordinal, flags });
     if (owner) n.shareSplats(this.handle, owner.handle);
+    else if (gaussians.plyPath) this.numGaussians = n.uploadPly(this.handle, gaussians.plyPath); // streaming loader: no packed buffer on the host
     else n.uploadSplats(this.handle, gaussians.gaussiansBuffer, this.numGaussians); // renderer.ts:130-137
     this.uniforms = new Float32Array(40);
+    // canvas.pipeline = K >= 2 (extension; the reference awaits every stage of every frame, renderer.ts:394-587): animate() still
+    // resolves once per frame and hands onFrame that frame's pixels, but it enqueues frame k+1 before frame k's pixels have
+    // arrived -- up to K frames are on the device at once -- and the pixels land in K page-locked sinks that are reused
+    // (a view handed to onFrame is valid until K more frames have been enqueued) instead of a fresh 8 MB ArrayBuffer per frame.
+    this.pipeline = Math.max(1, Math.min(4, (canvas.pipeline | 0) || 1));
+    this.sinks = null;
+    this.pending = []; // promises of the frames in flight, oldest first
+    this.slot = 0;
+    if (this.pipeline > 1) {
+      const bytes = canvas.width * canvas.height * 4;
+      this.sinks = [];
+      for (let k = 0; k < this.pipeline; ++k) this.sinks.push(new Uint8Array(n.hostAlloc(bytes)));
+    }
     this.autoSchedule = !(canvas.manual === true);
     if (this.autoSchedule) setImmediate(() => this.animate()); // requestAnimationFrame(() => this.animate()), renderer.ts:323
   }
@@ -59,19 +73,49 @@ class Renderer {
   destroyImpl() {
     if (this.destroyCallback === null) throw new Error('destroyImpl called without destroyCallback set!');
     if (!this.destroyed) {
-      loadNative().destroy(this.handle);
+      loadNative().destroy(this.handle); // (frames still in flight: the native side defers the teardown to their completion)
       this.destroyed = true;
     }
     this.destroyCallback();
   }
 
+  // One frame of the pipelined mode: enqueue now, resolve when THIS frame's pixels are in its sink.
+  animatePipelined() {
+    const n = loadNative();
+    const k = this.slot;
+    this.slot = (k + 1) % this.pipeline;
+    const sink = this.sinks[k];
+    const u = new Float32Array(this.uniforms); // this frame's block: `uniforms` is repacked by the next animate() before the enqueue below may run
+    const wait = this.pending.length >= this.pipeline ? this.pending.shift() : Promise.resolve();
+    // the sink of slot k is free once the frame that used it K frames ago has been delivered
+    const p = wait.then(() => {
+      if (this.destroyed) return undefined;
+      return n.renderToSink(this.handle, u, sink).then(() => {
+        this.numFrames++;
+        if (typeof this.canvas.onFrame === 'function') this.canvas.onFrame(sink, this.canvas.width, this.canvas.height);
+      });
+    });
+    this.pending.push(p.catch(() => {}));
+    return p;
+  }
+
   async animate() {
-    if (this.destroyCallback !== null) { this.destroyImpl(); return; }
+    if (this.destroyCallback !== null) {
+      if (this.pending.length) { await Promise.all(this.pending); this.pending = []; }
+      this.destroyImpl();
+      return;
+    }
     if (this.destroyed) return;
     const rearm = () => { if (this.autoSchedule) setImmediate(() => this.animate()); };
     if (!this.interactiveCamera.isDirty()) { rearm(); return; }
     const camera = this.interactiveCamera.getCamera();
     camera.packUniforms(this.canvas.width, this.canvas.height, this.uniforms); // renderer.ts:362-392
+    if (this.pipeline > 1) {
+      const p = this.animatePipelined(); // (the uniforms are copied by the native call before it returns)
+      rearm(); // the next frame may be enqueued at once
+      await p;
+      return;
+    }
     const n = loadNative();
     await n.renderAsync(this.handle, this.uniforms); // the whole frame, renderer.ts:394-574
     if (this.destroyed) return;

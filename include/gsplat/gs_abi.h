@@ -8,8 +8,16 @@
  * browser app); the N-API binding a Node host uses is gaussian-splatting-wgpu_amd/csrc/napi and
  * the binding stubs for other hosts are in INTEGRATION.md.
  *
- * Threading: a gs_ctx is not re-entrant (one frame in flight per ctx); different ctxs may be used
- * from different threads.  All device work of a ctx is ordered on one HIP stream.
+ * Threading: a gs_ctx is not re-entrant: its functions must not be called concurrently on the same ctx (the one exception is
+ * gs_wait_ticket, which another thread may call while the owner enqueues); different ctxs may be used from different threads.
+ * Frames in flight: a whole-canvas ctx on its own stream keeps up to GS_OPT_FRAMES_IN_FLIGHT (default 3) frames in flight -- a
+ * frame enqueued while the previous one is still on the device is rendered by a SHADOW of the ctx (own stream and per-frame
+ * arrays, the same resident splats), gs_render taking turns over that ring.  With K frames enqueued: gs_wait waits for ALL of
+ * them (and reports a capacity overflow of an earlier one as GS_ERR_TRUNCATED: only the last frame can be re-rendered);
+ * gs_read_rgba8, gs_read_buffer, gs_device_ptr and gs_get_stats describe the LAST frame enqueued (its ring member);
+ * gs_render_host / gs_wait_ticket address a frame of their own.  A host that calls gs_wait after every gs_render (as
+ * Renderer.animate does) never has more than one frame in flight and sees none of this.  Device work of one ring member is
+ * ordered on one HIP stream.
  * Ownership: the ctx owns every device allocation; host pointers passed in are copied before the
  * call returns; output host buffers are caller-allocated.
  */
@@ -170,6 +178,21 @@ int32_t gs_render_to(gs_ctx* ctx, const void* uniforms160, void* d_rgba8);
  * frames were enqueued since the last gs_wait and an EARLIER one overflowed, that frame cannot be re-rendered: the
  * capacity is grown for the following frames and GS_ERR_TRUNCATED is returned (the last frame is complete). */
 int32_t gs_wait(gs_ctx* ctx);
+
+/* Pipelined presentation (a host that does not await every frame, unlike renderer.ts:394-587): as gs_render, plus an asynchronous
+ * copy of the finished rgba8 slab image (height * slab_width * 4 bytes, <= size) into `host_dst` on the frame's own stream, so
+ * frame k+1 is enqueued -- and rendered by the next member of the ring -- while frame k is still being blended and copied.
+ * `host_dst` should come from gs_host_alloc (page-locked: the copy then overlaps the rendering; pageable memory also works, slower)
+ * and must stay untouched until gs_wait_ticket(*ticket) has returned.  Tickets count up from 1 per root ctx. */
+int32_t gs_render_host(gs_ctx* ctx, const void* uniforms160, void* host_dst, uint64_t size, uint64_t* ticket);
+/* Blocks until the frame of that ticket and its copy are complete.  May be called from another thread than the one that
+ * enqueues (one waiter per ticket).  A frame that overflowed a capacity is NOT re-rendered here: size the capacities first (render
+ * the scene's largest views once with gs_render + gs_wait, or pass gs_config.max_intersections); the next gs_wait reports it
+ * (GS_ERR_TRUNCATED).  At most 64 tickets may be outstanding. */
+int32_t gs_wait_ticket(gs_ctx* ctx, uint64_t ticket);
+/* Page-locked host memory for frame sinks. */
+int32_t gs_host_alloc(uint64_t bytes, void** out);
+void gs_host_free(void* p);
 
 /* Replaces the blit to the canvas (render.wgsl, renderer.ts:549-574): copies the finished rgba8
  * image of this ctx's slab to host memory; size must be height*slab_width*4. */

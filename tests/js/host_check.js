@@ -51,6 +51,80 @@ async function main() {
     const keys = new Uint32Array(r.readBuffer(g.BUF.KEYS));
     await r.destroy();
     console.log(JSON.stringify({ frames, numIntersections: r.numIntersections, stats: st, nkeys: keys.length, key0: keys.length ? keys[0] : 0 }));
+  } else if (cmd === 'pipeline') {
+    // pipeline <records.bin> <n> <W> <H> <tile> <uniforms.bin (K x 160 B)> <K>: K cameras through the pipelined animate() (canvas.pipeline = 3,
+    // pinned sinks, no await between the calls) must deliver, in order, the frames a synchronous render of each camera reads back
+    const rec = fs.readFileSync(process.argv[3]);
+    const n = parseInt(process.argv[4], 10), W = parseInt(process.argv[5], 10), H = parseInt(process.argv[6], 10), ts = parseInt(process.argv[7], 10);
+    const ub = fs.readFileSync(process.argv[8]);
+    const K = parseInt(process.argv[9], 10);
+    const us = [];
+    for (let k = 0; k < K; ++k) us.push(new Float32Array(ub.buffer.slice(ub.byteOffset + 160 * k, ub.byteOffset + 160 * (k + 1))));
+    const pg = g.PackedGaussians.fromRecords(rec.buffer.slice(rec.byteOffset, rec.byteOffset + rec.byteLength), n);
+    const idle = { isDirty() { return false; }, getCamera() { return null; } };
+    const a = new g.Renderer({ width: W, height: H, manual: true }, idle, { ordinal: 0 }, pg, ts);
+    const want = [];
+    for (let k = 0; k < K; ++k) { a.renderUniforms(us[k]); want.push(a.readPixels()); }
+    let step = 0;
+    const cam = { packUniforms: (w, h, o) => { o.set(us[step]); return o; } };
+    const ic = { isDirty() { return true; }, getCamera() { return cam; } };
+    const got = [];
+    const canvas = { width: W, height: H, manual: true, pipeline: 3, onFrame: (rgba) => { got.push(Uint8Array.from(rgba)); } };
+    const b = new g.Renderer(canvas, ic, { ordinal: 0, shareWith: a }, pg, ts);
+    for (let rep = 0; rep < 2; ++rep) for (let k = 0; k < K; ++k) b.renderUniforms(us[k]); // capacities
+    const ps = [];
+    for (let k = 0; k < K; ++k) { step = k; ps.push(b.animate()); }
+    await Promise.all(ps);
+    let same = got.length === K;
+    for (let k = 0; same && k < K; ++k) {
+      same = got[k].length === want[k].length;
+      for (let i = 0; same && i < want[k].length; ++i) same = got[k][i] === want[k][i];
+    }
+    const frames = b.numFrames;
+    await b.destroy(); await a.destroy();
+    console.log(JSON.stringify({ same, delivered: got.length, frames }));
+  } else if (cmd === 'bench') {
+    // bench <scene.ply> <W> <H> <tile> <orbit.bin (64 x 160 B)> <frames> : frames/s of Renderer.animate() with a dirty camera every frame,
+    //   (a) as the reference drives it: await animate() per frame, no frame sink;  (b) the same with an onFrame sink (8 MB read-back + a
+    //   fresh Uint8Array per frame);  (c) canvas.pipeline = 3: pinned sinks, frame k+1 enqueued before frame k's pixels have arrived
+    const W = parseInt(process.argv[4], 10), H = parseInt(process.argv[5], 10), ts = parseInt(process.argv[6], 10);
+    const ob = fs.readFileSync(process.argv[7]);
+    const frames = parseInt(process.argv[8], 10);
+    const orbit = [];
+    for (let k = 0; k < 64; ++k) orbit.push(new Float32Array(ob.buffer.slice(ob.byteOffset + 160 * k, ob.byteOffset + 160 * (k + 1))));
+    const out = {};
+    let owner = null;
+    for (const mode of ['await_no_sink', 'await_with_sink', 'pipeline3_pinned_sinks']) {
+      let step = 0, delivered = 0, sum = 0;
+      const cam = { packUniforms: (w, h, o) => { o.set(orbit[step % 64]); return o; } };
+      const ic = { isDirty() { return true; }, getCamera() { return cam; } };
+      const canvas = { width: W, height: H, manual: true };
+      if (mode !== 'await_no_sink') canvas.onFrame = (rgba) => { delivered++; sum += rgba[(delivered * 7919) % rgba.length]; };
+      if (mode === 'pipeline3_pinned_sinks') canvas.pipeline = 3;
+      const dev = owner ? { ordinal: 0, shareWith: owner } : { ordinal: 0 };
+      const r = new g.Renderer(canvas, ic, dev, { numGaussians: 0, plyPath: process.argv[3] }, ts);
+      if (!owner) owner = r;
+      for (let rep = 0; rep < 2; ++rep) // capacities of every member of the ring for the whole orbit (outside the timed loop)
+        for (let k = 0; k < 64; ++k) r.renderUniforms(orbit[k]);
+      const run = async (n) => {
+        const inflight = [];
+        for (let i = 0; i < n; ++i) {
+          step = i;
+          const p = r.animate();
+          if (r.pipeline > 1) { inflight.push(p); if (inflight.length >= r.pipeline) await inflight.shift(); } else await p;
+        }
+        await Promise.all(inflight);
+      };
+      await run(20);
+      const t0 = process.hrtime.bigint();
+      await run(frames);
+      const dt = Number(process.hrtime.bigint() - t0) / 1e9;
+      out[mode] = { frames, fps: frames / dt, ms_per_frame: dt / frames * 1e3, delivered, checksum: sum };
+      if (r !== owner) await r.destroy();
+    }
+    out.numGaussians = owner.numGaussians;
+    await owner.destroy();
+    console.log(JSON.stringify(out));
   } else if (cmd === 'shared') {
     // shared <records.bin> <n> <W> <H> <tile> <uniforms.bin>: a second renderer borrows the first one's splats
     const rec = fs.readFileSync(process.argv[3]);

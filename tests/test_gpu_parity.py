@@ -435,6 +435,52 @@ def test_frames_in_flight_match_sequential(oracle):
     seq.destroy()
 
 
+def test_render_host_tickets(oracle):
+    """gs_render_host / gs_wait_ticket (pipelined presentation): frames enqueued back to back, each with an asynchronous copy of its
+    pixels into its own page-locked sink; tickets waited for out of order; every sink holds exactly what a sequential render of
+    that camera reads back."""
+    import ctypes
+    from gsplat import _abi
+    L = _abi.load()
+    n, W, H = 60000, 640, 360
+    s = scene(n)
+    us = [_uniforms(W, H, step=k) for k in range(7)]
+    seq = _mk(s, W, H, 16)
+    seq.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)
+    want = []
+    for u in us:
+        seq.render_uniforms(u); seq.wait()
+        want.append(seq.read_rgba8())
+    seq.destroy()
+    r = _mk(s, W, H, 16)
+    for u in us:  # capacities of every member of the ring
+        r.render_uniforms(u)
+    r.wait()
+    nbytes = W * H * 4
+    sinks, tickets = [], []
+    for _ in us:
+        p = ctypes.c_void_p()
+        _abi.check(L.gs_host_alloc(nbytes, ctypes.byref(p)))
+        sinks.append(p)
+    for u, p in zip(us, sinks):
+        t = ctypes.c_uint64()
+        uu = np.ascontiguousarray(u, dtype=np.float32)
+        _abi.check(L.gs_render_host(r._ctx, uu.ctypes.data, p, nbytes, ctypes.byref(t)))
+        tickets.append(t.value)
+    assert tickets == list(range(tickets[0], tickets[0] + len(us)))
+    for k in (3, 0, 6, 1, 2, 5, 4):
+        _abi.check(L.gs_wait_ticket(r._ctx, tickets[k]))
+        got = np.ctypeslib.as_array(ctypes.cast(sinks[k], ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)).reshape(H, W, 4)
+        np.testing.assert_array_equal(got, want[k])
+    with pytest.raises(_abi.GsError):
+        _abi.check(L.gs_wait_ticket(r._ctx, tickets[-1] + 1))  # never issued
+    r.wait()
+    assert r.stats()["frames_in_flight"] >= 2
+    r.destroy()
+    for p in sinks:
+        L.gs_host_free(p)
+
+
 def test_frame_graph_replays_the_same_frames():
     """GS_OPT_FRAME_GRAPH: frames replayed from the captured hipGraph (uniforms patched into the projection's node) are the
     frames the directly issued launches give -- moving camera, an option change (re-capture), a capacity regrow on the first

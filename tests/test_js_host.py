@@ -131,6 +131,22 @@ def test_renderer_animate_end_to_end(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_renderer_pipelined_animate_delivers_every_frame_in_order(tmp_path):
+    """canvas.pipeline = 3 (extension of the reference's class surface): six animate() calls without awaiting in between; every
+    frame arrives once, in order, in a page-locked sink, equal to the synchronous render of its camera (N-API renderToSink /
+    hostAlloc over gs_render_host / gs_wait_ticket / gs_host_alloc)."""
+    from gsplat import synth
+    n, W, H, ts, K = 8000, 256, 160, 16, 6
+    s = scene(n)
+    us = np.stack([synth.orbit_camera(3 * k, W, H).uniforms(W, H) for k in range(K)]).astype(np.float32)
+    rec, ub = str(tmp_path / "rec.bin"), str(tmp_path / "u.bin")
+    s.tofile(rec)
+    us.tofile(ub)
+    info = _node("pipeline", rec, n, W, H, ts, ub, K)
+    assert info["same"] and info["delivered"] == K and info["frames"] >= K
+
+
+@pytest.mark.gpu
 def test_renderer_shares_splats(tmp_path):
     """device.shareWith: a second Renderer borrows the first one's resident splats (gs_share_splats) and draws the same frame."""
     from gsplat import synth
