@@ -27,9 +27,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, profiling=False):
+    """profiling=True: -DGS_PROFILING, a separate libgsplat_hip_prof.so with the blend's ablation branches and per-walker stamps
+    (tools/blend_profile.py, tools/sweep.sh); the product library does not contain them."""
     os.makedirs(OUT, exist_ok=True)
-    objdir = os.path.join(OUT, "obj")
+    objdir = os.path.join(OUT, "obj_prof" if profiling else "obj")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(HERE, h) for h in ("gs_device.h", "gs_kernels.h", "gs_tight.h")] + [
         os.path.join(HERE, "..", "..", "include", "gsplat", "gs_abi.h")]
@@ -38,7 +40,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(HERE, src)
         if force or _stale(obj, [path] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+            cmd = [HIPCC] + FLAGS + (["-DGS_PROFILING"] if profiling else []) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -46,14 +48,14 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    so = os.path.join(OUT, "libgsplat_hip.so")
+    so = os.path.join(OUT, "libgsplat_hip_prof.so" if profiling else "libgsplat_hip.so")
     if force or _stale(so, objs):
         subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs)
     return os.path.abspath(so)
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, profiling="--profiling" in sys.argv))
 
 
 def build_napi(force=False, verbose=False):

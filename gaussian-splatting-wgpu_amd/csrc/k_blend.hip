@@ -107,7 +107,9 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
         for (int i = 0; i < 4; ++i) {
             const uint32_t rec = qrec + 16u * i; // entry (w*64 + rec) of the batch
             uint32_t g = __shfl(gval, rec, 64) & id_mask; // tight frames: the sub-block mask rides in the high bits (gs_tight.h)
-            if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION): gather from a cache-resident window
+#ifdef GS_PROFILING
+            if (dbg & 2u) g &= 1023u; // gather from a cache-resident window
+#endif
             if (b + w * 64u + rec < end && piece < 3u) rq[i] = gdata[(uint64_t)g * 4 + piece];
         }
     };
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
         }
         const uint32_t cnt = (end - b < (uint32_t)NT) ? end - b : (uint32_t)NT;
         staged += cnt;
-        if (__ballot(!done) != 0ull && !(dbg & 4u)) { // otherwise this wave's 8x8 block is final (uniform per wave)
+        if (__ballot(!done) != 0ull) { // otherwise this wave's 8x8 block is final (uniform per wave)
 #pragma unroll 1
             for (int r = 0; r < ROUNDS; ++r) {
                 const uint32_t e0 = (uint32_t)r * 64u;
@@ -174,7 +176,9 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
                     float mag;
                     const float q = block_qmin(p1.x, p1.y, p1.z, dxlo, dxhi, dylo, dyhi, mag);
                     rel = !pd || !(q > p0.z + 1.0e-5f * mag); // NaNs compare false -> relevant
-                    if (dbg & 1u) rel = false; // PROFILING ONLY: staging + cull cost without the pixel loop
+#ifdef GS_PROFILING
+                    if (dbg & 1u) rel = false; // staging + cull cost without the pixel loop
+#endif
                 }
                 unsigned long long m = __ballot(rel);
                 evaluated += (uint32_t)__popcll(m);
@@ -244,172 +248,11 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Single-wave variant for 16x16 tiles: ONE wave owns the whole tile, four pixels per lane (one in
-// each 8x8 quadrant).  No workgroup barrier exists at all, so the eight waves resident on a SIMD are
-// eight independent gather -> cull -> blend pipelines that hide each other's memory latency; every
-// list entry is still gathered exactly once per tile.  Per 64-entry batch each lane converts the
-// entry it fetched, tests it against the four quadrants (four masks), parks it in the wave's private
-// LDS slot, and the wave then walks the four masks in turn.  Used when the launch has enough tiles to
-// fill the chip with whole-tile waves (otherwise the 4-wave kernel above gives more parallelism per tile).
-// ------------------------------------------------------------------------------------------------
-template <bool EXACT>
-__global__ __launch_bounds__(64) void gs_blend_wave_kernel(const uint4* __restrict__ gdata, const uint32_t* __restrict__ values,
-                                                            const uint32_t* __restrict__ ranges, GsFrame f,
-                                                            uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
-                                                            uint32_t dbg, uint32_t id_mask) {
-    constexpr int TS = 16;
-    __shared__ float4 sP0[64]; // gx, gy, -, -
-    __shared__ float4 sP1[64]; // conic (fused mode: pre-scaled), -
-    __shared__ float4 sP2[64]; // r, g, b, opacity
-    const uint32_t lane = threadIdx.x;
-    const uint32_t tx = f.col0 + blockIdx.x, ty = blockIdx.y;
-    const uint32_t tile = tx + ty * f.ntx;
-    const uint32_t start = tile > 0 ? ranges[tile - 1] : 0u;
-    uint32_t end = ranges[tile];
-    if (end > f.capacity) end = f.capacity;
-    const float c255 = (float)(1.0 / 255.0);
-    const float Wf = (float)f.width, Hf = (float)f.height;
-    const float tx0f = (float)(tx * TS), ty0f = (float)(ty * TS);
-
-    float pxf[4], pyf[4], T[4], cr[4], cg[4], cb[4];
-    bool outside[4], done[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t gx = tx * TS + (q & 1) * 8 + (lane & 7), gy = ty * TS + (q >> 1) * 8 + (lane >> 3);
-        pxf[q] = (float)gx;
-        pyf[q] = (float)gy;
-        T[q] = 1.0f;
-        cr[q] = cg[q] = cb[q] = 0.0f;
-        outside[q] = !(gx < f.width && gy < f.height);
-        done[q] = outside[q];
-    }
-    uint32_t staged = 0, evaluated = 0;
-
-    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
-    uint32_t gnext = 0;
-    auto fetch_id = [&](uint32_t b) { gnext = (b + lane < end) ? values[b + lane] : 0u; };
-    auto fetch = [&](uint32_t b, uint32_t g) {
-        if (b + lane < end) {
-            g &= id_mask;
-            if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
-            r0 = gdata[(uint64_t)g * 4 + 0];
-            r1 = gdata[(uint64_t)g * 4 + 1];
-            r2 = gdata[(uint64_t)g * 4 + 2];
-        }
-    };
-    if (start < end) {
-        fetch_id(start);
-        fetch(start, gnext);
-        fetch_id(start + 64);
-    }
-    for (uint32_t b = start; b < end; b += 64) {
-        // convert the entry this lane fetched and test it against the four quadrants
-        const uint32_t cnt = (end - b < 64u) ? end - b : 64u;
-        staged += cnt;
-        bool rel[4] = {false, false, false, false};
-        if (lane < cnt) {
-            const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
-            const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
-            const float op = __uint_as_float(r2.w);
-            const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
-            const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float dxhi = gxp - (tx0f + (float)((q & 1) * 8)), dyhi = gyp - (ty0f + (float)((q >> 1) * 8));
-                float mag;
-                const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
-                rel[q] = !pd || !(qm > lim + 1.0e-5f * mag);
-            }
-            const float L = 1.44269502162933349609375f;
-            sP0[lane] = make_float4(gxp, gyp, 0.0f, 0.0f);
-            sP1[lane] = EXACT ? make_float4(cx, cy, cz, 0.0f) : make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, 0.0f);
-            sP2[lane] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
-        }
-        // next batch's gathers go out now and land while this batch is blended
-        const uint32_t nb = b + 64;
-        if (nb < end) {
-            const uint32_t g = gnext;
-            fetch(nb, g);
-            fetch_id(nb + 64);
-        }
-        // one wave: LDS writes above are visible to its own later reads (in-order LDS); compiler fence only
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        bool all_done = true;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned long long m = __ballot(rel[q] && !(dbg & 1u));
-            if (__ballot(!done[q]) == 0ull) m = 0ull; // this quadrant is final
-            evaluated += (uint32_t)__popcll(m);
-            while (m) {
-                const uint32_t e = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1ull;
-                const float4 p0 = sP0[e];
-                const float4 p1 = sP1[e];
-                const float4 p2v = sP2[e];
-                const float dx = p0.x - pxf[q], dy = p0.y - pyf[q];
-                if (EXACT) {
-                    const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
-                    const float power = -0.5f * (t1 + t2) - t3;
-                    const float alpha = wg_min(0.99f, p2v.w * gs_exp(power));
-                    const float test = T[q] * (1.0f - alpha);
-                    const float cond = (power <= 0.0f && alpha >= c255 && test >= 0.0001f) ? 1.0f : 0.0f;
-                    cr[q] += cond * p2v.x * alpha * T[q];
-                    cg[q] += cond * p2v.y * alpha * T[q];
-                    cb[q] += cond * p2v.z * alpha * T[q];
-                    T[q] = cond * test + (1.0f - cond) * T[q];
-                } else {
-                    const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
-                    const float v = (p1.z * dy) * dy;
-                    const float pw = __builtin_fmaf(dx, u, v); // power * log2(e)
-                    const float alpha = __builtin_fminf(0.99f, p2v.w * __builtin_amdgcn_exp2f(pw));
-                    const float test = __builtin_fmaf(-T[q], alpha, T[q]);
-                    const bool keep = (pw <= 0.0f) && (alpha >= c255) && (test >= 0.0001f);
-                    const float wgt = (keep ? alpha : 0.0f) * T[q];
-                    cr[q] = __builtin_fmaf(p2v.x, wgt, cr[q]);
-                    cg[q] = __builtin_fmaf(p2v.y, wgt, cg[q]);
-                    cb[q] = __builtin_fmaf(p2v.z, wgt, cb[q]);
-                    T[q] = keep ? test : T[q];
-                }
-            }
-            if (EXACT) done[q] = outside[q] || (T[q] * (1.0f - c255) < 0.0001f);
-            else done[q] = outside[q] || (__builtin_fmaf(-T[q], c255, T[q]) < 0.0001f);
-            all_done = all_done && done[q];
-        }
-        // the LDS slots are rewritten next iteration: all reads above have been issued by this wave already
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (__ballot(!all_done) == 0ull) break; // every pixel of the tile is final (exact criterion)
-    }
-    if (lane == 0 && staged) atomicAdd(&ctl->num_processed[(blockIdx.x + blockIdx.y * gridDim.x) & 63u], (unsigned long long)staged);
-    if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(blockIdx.x + blockIdx.y * gridDim.x + 1u) & 63u], (unsigned long long)evaluated);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (outside[q]) continue;
-        const uint32_t gx = tx * TS + (q & 1) * 8 + (lane & 7), gy = ty * TS + (q >> 1) * 8 + (lane >> 3);
-        const float c[3] = {cr[q], cg[q], cb[q]};
-        uint32_t px = 0xFF000000u;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float v = c[ch];
-            v = (v != v) ? 0.0f : wg_min(wg_max(v, 0.0f), 1.0f);
-            px |= (uint32_t)__builtin_floorf(v * 255.0f + 0.5f) << (8 * ch);
-        }
-        const uint64_t o = (uint64_t)gy * f.slab_w + (gx - f.px0);
-        rgba8[o] = px;
-        if (rgbf) {
-            rgbf[o * 3 + 0] = cr[q];
-            rgbf[o * 3 + 1] = cg[q];
-            rgbf[o * 3 + 2] = cb[q];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Quadrant variant: one single-wave workgroup per 8x8 pixel block of a 16x16 tile, each walking the
-// tile's list on its own.  Four times as many, four times shorter pipelines than the whole-tile wave
-// kernel: the dispatcher keeps refilling the SIMDs until the end of the launch instead of letting
-// the occupancy decay as the 8 160 whole-tile waves retire, and a block stops as soon as ITS 64
+// Quadrant variant (the default): one single-wave workgroup per 8x8 pixel block of a 16x16 tile, each walking
+// the tile's list on its own: no workgroup barrier anywhere, the eight waves resident on a SIMD are eight
+// independent gather -> park -> blend pipelines that hide each other's memory latency; 32 640 short
+// pipelines keep the dispatcher refilling the SIMDs until the end of the launch (round 1's one wave per
+// whole tile let the occupancy decay as its 8 160 waves retired), and a block stops as soon as ITS 64
 // pixels are final.  The four blocks of a tile are workgroups b, b+8, b+16, b+24 (the same XCD under
 // round-robin placement) so the three extra gathers of every record are normally L2 hits; placement
 // only affects speed.
@@ -427,8 +270,9 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                                                             uint32_t* __restrict__ rgba8, float* __restrict__ rgbf, GsControl* ctl,
                                                             uint32_t* __restrict__ tile_depth, uint32_t dbg, uint32_t* __restrict__ prof) {
     constexpr uint32_t BPR = TS / 8, NB = BPR * BPR;
-    // PROFILING ONLY (prof != nullptr, GS_OPT_BLEND_ABLATION bit 16): start / end stamp (100 MHz), evaluated and staged entries per walker
-    const uint32_t t_start = prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; // 8x8 pixel blocks per tile row / per tile (4 at tile 16, 16 at tile 32)
+#ifdef GS_PROFILING // (build.py --profiling; GS_OPT_BLEND_ABLATION bit 16): start / end stamp (100 MHz), evaluated and staged entries per walker
+    const uint32_t t_start = prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+#endif
     __shared__ float4 sP0[64];
     __shared__ float4 sP1[64];
     __shared__ float4 sP2[64];
@@ -485,7 +329,9 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         bool want = bb + lane < end;
         if (MASKED) want = want && ((v >> mybit) & 1u);
         uint32_t g = MASKED ? (v & GS_ID_MASK) : v;
-        if (dbg & 2u) g &= 1023u; // PROFILING ONLY (GS_OPT_BLEND_ABLATION)
+#ifdef GS_PROFILING
+        if (dbg & 2u) g &= 1023u; // gather from a cache-resident window
+#endif
         g = want ? g : 0u;
         const uint32_t* rec = reinterpret_cast<const uint32_t*>(gdata + (uint64_t)g * 4);
         r0 = *reinterpret_cast<const gs_u32x2*>(rec);
@@ -516,10 +362,13 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 const float dxhi = gxp - bx0f, dyhi = gyp - by0f;
                 float mag;
                 const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
-                rel = (!pd || !(qm > lim + 1.0e-5f * mag)) && !(dbg & 1u);
+                rel = !pd || !(qm > lim + 1.0e-5f * mag);
             } else {
-                rel = !(dbg & 1u); // the emission already decided it for exactly these 64 pixels
+                rel = true; // the binning already decided it for exactly these 64 pixels
             }
+#ifdef GS_PROFILING
+            if (dbg & 1u) rel = false; // staging cost without the pixel loop
+#endif
             npd = rel && !pd;
         }
         // only surviving entries are parked for the broadcast, DENSELY (slot = rank among the survivors, list order kept): the
@@ -629,12 +478,14 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     // (tile_depth[] is zeroed with the control block; the host sums it)
     if (lane == 0 && staged) atomicMax(&tile_depth[lin], staged);
     if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(b + 1u) & 63u], (unsigned long long)evaluated);
+#ifdef GS_PROFILING
     if (prof && lane == 0) {
         prof[b * 4u + 0u] = t_start;
         prof[b * 4u + 1u] = (uint32_t)__builtin_amdgcn_s_memrealtime();
         prof[b * 4u + 2u] = evaluated;
         prof[b * 4u + 3u] = staged;
     }
+#endif
     if (!outside) {
         const float c[3] = {cr, cg, cb};
         uint32_t px = 0xFF000000u;
@@ -737,13 +588,10 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
     case 8: launch_blend_t<8>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1;
     case 16:
     case 32: {
-        // ablation bit 3 forces the 4-wave kernel, bit 4 the single-wave kernel; default: whole-tile waves once
-        // the launch has >= 4 tiles per SIMD (1024 SIMDs), else the 4-wave kernel (slabs, small canvases)
-        // default: one single-wave workgroup per 8x8 quadrant; ablation bits force the others
-        // (8 = 4-wave workgroup per tile, 16 = one wave per whole tile)
-        const bool wave = (dbg & 16u) != 0;
+        // default: one single-wave workgroup per 8x8 pixel block; GS_OPT_BLEND_ABLATION bit 3 picks the workgroup-per-tile kernel
+        // (identical results: the tile-8 kernel instantiated for tile 16 / 32)
         const bool t32 = f.tile_size == 32;
-        if (!(dbg & (8u | 16u)) || (t32 && !(dbg & 8u))) {
+        if (!(dbg & 8u)) {
             // strip width: the widest of 3, 2, 1 tile columns that still spreads the slab's columns evenly over the 8 XCDs
             // (120 or 240 columns -> 3; a 60-column slab -> 2; 30- and 15-column slabs -> 1); GS_OPT_BLEND_ABLATION
             // bits 8..15 override it
@@ -768,17 +616,19 @@ int gs_launch_blend(const void* gdata, const uint32_t* values, const uint32_t* r
             const uint32_t nblk = (t32 ? 128u : 32u) * wmax * grid.y;
             // PROFILING ONLY: bits 6/7 reserve dynamic LDS so that only 2 / 4 waves fit a SIMD (occupancy sensitivity:
             // config B 8 waves -> 982 us, 4 -> 1214, 2 -> 1890)
+#ifdef GS_PROFILING
             const uint32_t pad = (dbg & 64u) ? 20480u - 3072u : (dbg & 128u) ? 10240u - 3072u : 0u;
+#else
+            const uint32_t pad = 0u;
+#endif
             if (prof_blocks) *prof_blocks = nblk;
             if (t32) { launch_quad_t<32>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg, prof); return 16; }
             launch_quad_t<16>(exact, masked, nblk, pad, st, g, values, ranges, f, rgba8, rgbf, ctl, tile_depth, dbg, prof);
             return 4;
         }
         if (t32) { launch_blend_t<32>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1; } // ablation bit 3: 1024-thread workgroup per tile
-        if (!wave) { launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask); return 1; }
-        if (exact) hipLaunchKernelGGL((gs_blend_wave_kernel<true>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
-        else hipLaunchKernelGGL((gs_blend_wave_kernel<false>), grid, dim3(64), 0, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
-        return 0;
+        launch_blend_t<16>(exact, grid, st, g, values, ranges, f, rgba8, rgbf, ctl, dbg, id_mask);
+        return 1;
     }
     default: return -1;
     }
