@@ -273,9 +273,15 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
 #ifdef GS_PROFILING // (build.py --profiling; GS_OPT_BLEND_ABLATION bit 16): start / end stamp (100 MHz), evaluated and staged entries per walker
     const uint32_t t_start = prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
 #endif
-    __shared__ float4 sP0[64];
-    __shared__ float4 sP1[64];
-    __shared__ float4 sP2[64];
+    __shared__ float4 sP0[64];                 // EXACT: gx gy - -      fused: gx, conic.x', r, g
+    __shared__ float4 sP1[EXACT ? 64 : 1];     // EXACT: conic
+    __shared__ float4 sP2[EXACT ? 64 : 1];     // EXACT: r g b opacity
+    __shared__ float2 sB[EXACT ? 1 : 64];      // fused: b, log2(opacity)
+    // fused: the part of the exponent that depends on the pixel ROW only -- (conic.y' dy, conic.z' dy^2 + log2 opacity) for the 8
+    // rows of the block, tabulated by the lane that parks the entry.  dy takes 8 values in an 8x8 block: evaluating those two
+    // terms per (entry, pixel) spent 4 of the loop's 17 VALU instructions on 8-fold redundant work.  Rows are 65 slots apart:
+    // the 8 rows of a slot then sit in 8 different bank pairs (ds_read_b64).
+    __shared__ float2 sT[EXACT ? 1 : 8 * 65];
     const uint32_t lane = threadIdx.x;
     const uint32_t slab_tx = f.col1 - f.col0;
     // Workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own L2.  XCD x owns the column strips
@@ -386,9 +392,14 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 sP1[slot] = make_float4(cx, cy, cz, 0.0f);
                 sP2[slot] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
             } else {
-                sP0[slot] = make_float4(gxp, gyp, __uint_as_float(r2.x), __uint_as_float(r2.y));
-                sP1[slot] = make_float4((-0.5f * L) * cx, (-L) * cy, (-0.5f * L) * cz, __builtin_amdgcn_logf(op));
-                sP2[slot].x = __uint_as_float(r2.z); // 16-byte stride: one address register serves all three reads
+                const float hx = (-0.5f * L) * cx, hy = (-L) * cy, hz = (-0.5f * L) * cz, lop = __builtin_amdgcn_logf(op);
+                sP0[slot] = make_float4(gxp, hx, __uint_as_float(r2.x), __uint_as_float(r2.y));
+                sB[slot] = make_float2(__uint_as_float(r2.z), lop);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { // the same operations, in the same order, as the per-pixel form they replace
+                    const float dy = gyp - (by0f + (float)r);
+                    sT[r * 65 + slot] = make_float2(hy * dy, __builtin_fmaf(hz * dy, dy, lop));
+                }
             }
         }
         const uint32_t nb = bb + 64;
@@ -405,13 +416,15 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         // rounding, which the oracle's ill-conditioning margin covers), so the fused loop only pays for that compare in
         // a batch that holds a survivor with a non-positive-definite conic (never produced by the projection's +0.3
         // low-pass; NaN records land here too).
+        const uint32_t trow = (lane >> 3) * 65u;
         auto walk = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
             auto one = [&](uint32_t e) {
                 const float4 p0 = sP0[e];
-                const float4 p1 = sP1[e];
-                const float dx = p0.x - pxf, dy = p0.y - pyf;
+                const float dx = p0.x - pxf;
                 if (EXACT) {
+                    const float4 p1 = sP1[e];
+                    const float dy = p0.y - pyf;
                     const float4 p2v = sP2[e];
                     const float t1 = p1.x * dx * dx, t2 = p1.z * dy * dy, t3 = p1.y * dx * dy;
                     const float power = -0.5f * (t1 + t2) - t3;
@@ -423,15 +436,16 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     cb += cond * p2v.z * alpha * T;
                     T = cond * test + (1.0f - cond) * T;
                 } else {
-                    const float colb = sP2[e].x;
-                    const float u = __builtin_fmaf(p1.x, dx, p1.y * dy);
-                    const float v = __builtin_fmaf(p1.z * dy, dy, p1.w);
-                    const float pw = __builtin_fmaf(dx, u, v); // power * log2(e) + log2(op)
+                    const float2 bl = sB[e];
+                    const float colb = bl.x;
+                    const float2 tt = sT[trow + e];            // this pixel row's (conic.y' dy, conic.z' dy^2 + log2 op)
+                    const float u = __builtin_fmaf(p0.y, dx, tt.x);
+                    const float pw = __builtin_fmaf(dx, u, tt.y); // power * log2(e) + log2(op)
                     const float alpha = __builtin_fminf(0.99f, __builtin_amdgcn_exp2f(pw));
                     const float test = __builtin_fmaf(-T, alpha, T);
                     if (CHECKED) {
                         bool keep = (alpha >= c255) && (test >= 0.0001f);
-                        keep = keep && (pw <= p1.w); // power <= 0
+                        keep = keep && (pw <= bl.y); // power <= 0
                         const float wgt = (keep ? alpha : 0.0f) * T;
                         cr = __builtin_fmaf(p0.z, wgt, cr);
                         cg = __builtin_fmaf(p0.w, wgt, cg);

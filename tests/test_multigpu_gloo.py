@@ -306,7 +306,7 @@ def test_pipelined_slabs_over_rccl_world_of_one(tmp_path, collective):
     assert np.load(out)[0] == 1, "the frame gathered and assembled over RCCL differs from the whole-canvas frame"
 
 
-def _gpu_groups_worker(rank, world, port, W, H, ts, out, groups):
+def _gpu_groups_worker(rank, world, port, W, H, ts, out, groups, backend="gloo"):
     """multigpu.FrameGroupSlabs: groups of ranks render alternate frames, every frame = world/groups slabs gathered to rank 0."""
     import torch
     import torch.distributed as dist
@@ -314,9 +314,13 @@ def _gpu_groups_worker(rank, world, port, W, H, ts, out, groups):
     from gsplat import _abi, multigpu, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     s = synth.bicycle_like(60000)
     us = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(9)]
     pg = gsplat.PackedGaussians(s)
@@ -352,3 +356,15 @@ def test_frame_groups_on_one_gpu(tmp_path):
     port = 29500 + (os.getpid() % 2000) + 50
     mp.spawn(_gpu_groups_worker, args=(4, port, 640, 368, 16, out, 2), nprocs=4, join=True)
     assert np.load(out)[0] == 1, "a frame gathered from a frame group differs from the whole-canvas frame"
+
+
+@pytest.mark.gpu
+def test_frame_groups_over_rccl_world_of_one(tmp_path):
+    """FrameGroupSlabs' own code -- dist.new_group, the gather on a sub-communicator, the assembly on the communication stream --
+    on the nccl (= RCCL) backend with a world of one rank: all the one-GPU box can execute of it (more ranks over RCCL need more
+    GPUs; over gloo: test_frame_groups_on_one_gpu)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    port = 29500 + (os.getpid() % 2000) + 60
+    mp.spawn(_gpu_groups_worker, args=(1, port, 640, 368, 16, out, 1, "nccl"), nprocs=1, join=True)
+    assert np.load(out)[0] == 1, "the frame gathered by FrameGroupSlabs over RCCL differs from the whole-canvas frame"
