@@ -53,6 +53,37 @@ __device__ __forceinline__ uint32_t gs_rowhist(const GsControl* ctl, uint32_t r)
     return s;
 }
 
+// What gs_wait needs to know about a frame, written by ONE thread of the frame's last binning kernel straight into host-mapped
+// (page-locked) memory: no device-to-host copy is enqueued per frame (round 2: two copy kernels of ~4.7 us each behind every
+// blend).  sticky: words that survive the per-frame memset -- every frame folds its flags into them, so the report of the last
+// frame of a batch also tells about the frames enqueued before it ([0] frames that overflowed a capacity, [1] a bounded spin
+// gave up, [2] largest instance count, [3] largest arena demand in slots).
+struct GsReport {
+    uint32_t fault, overflow, num_intersections, num_visible, num_slots, num_items, pad0, pad1;
+    uint32_t row_cursor[16];
+    uint32_t sticky[4];
+};
+__device__ __forceinline__ void gs_frame_report(const GsControl* ctl, uint32_t I, uint32_t num_items, uint32_t capacity, uint32_t* sticky,
+                                                GsReport* rep) {
+    uint32_t need = 0; // arena slots this frame would have needed: 16 shards as large as the fullest one
+    for (int k = 0; k < 16; ++k) need = ctl->row_cursor[k] > need ? ctl->row_cursor[k] : need;
+    need = need > 0x07FFFFFFu ? 0x7FFFFFFFu : need * 16u;
+    const uint32_t over = (I > capacity || ctl->overflow) ? 1u : 0u;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (sticky) {
+        s0 = atomicAdd(&sticky[0], over) + over;
+        s1 = atomicOr(&sticky[1], ctl->fault ? 1u : 0u) | (ctl->fault ? 1u : 0u);
+        s2 = atomicMax(&sticky[2], I); s2 = s2 > I ? s2 : I;
+        s3 = atomicMax(&sticky[3], need); s3 = s3 > need ? s3 : need;
+    }
+    if (rep) {
+        rep->fault = ctl->fault; rep->overflow = over; rep->num_intersections = I; rep->num_visible = ctl->num_visible;
+        rep->num_slots = ctl->num_slots; rep->num_items = num_items;
+        for (int k = 0; k < 16; ++k) rep->row_cursor[k] = ctl->row_cursor[k];
+        rep->sticky[0] = s0; rep->sticky[1] = s1; rep->sticky[2] = s2; rep->sticky[3] = s3;
+    }
+}
+
 struct GsTightOut { // product-path outputs of the tight projection beside GaussianData and the count words (k_preprocess.hip)
     uint32_t* arena; uint32_t* rowptr; GsControl* ctl;
 };

@@ -24,11 +24,11 @@ void gs_launch_emit_balanced(const void* gdata, const void* grec, const uint32_t
 void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* offsets, const uint32_t* perm, const uint32_t* n_dev,
                     const GsFrame& f, uint32_t* keys, uint32_t* values, GsControl* ctl, hipStream_t st);
 void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                        uint32_t* sticky, hipStream_t st);
+                        uint32_t* sticky, GsReport* rep, hipStream_t st);
 void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t id_mask,
                             uint32_t* keys, hipStream_t st);
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                      uint32_t* sticky, hipStream_t st);
+                      uint32_t* sticky, GsReport* rep, hipStream_t st);
 uint32_t gs_sort_tiles(uint64_t capacity);
 void gs_launch_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, GsControl* ctl, uint32_t* tickets, uint32_t* hist,
                     const uint32_t* n_ptr, uint32_t capacity, uint32_t passes, uint32_t bits, uint32_t by_tile, uint32_t* status,
@@ -50,6 +50,6 @@ uint32_t gs_rows_sort_tiles(uint64_t row_cap);
 uint32_t gs_rows_chunks(uint64_t row_cap);
 void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chunk_table, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
                     uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
-                    uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg);
+                    uint32_t* sticky, GsReport* rep, hipStream_t st, void (*mark)(void*, int), void* mark_arg);
 void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,
                                  uint32_t* keys, hipStream_t st);

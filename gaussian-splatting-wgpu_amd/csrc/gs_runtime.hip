@@ -136,9 +136,12 @@ struct gs_ctx {
     uint32_t last_passes = 0;
     bool last_by_index = true;
     uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
-    GsControl* h_ctl = nullptr; // pinned
-    uint32_t* sticky = nullptr;   // device: [0] frames that overflowed, [1] fault, [2] largest I -- NOT in the per-frame memset (k_binning.hip fold_sticky)
-    uint32_t* h_sticky = nullptr; // pinned copy, refreshed by every frame
+    GsControl* h_ctl = nullptr; // pinned copy of the control block's counters, fetched on demand (gs_get_stats)
+    bool h_ctl_valid = false;
+    GsReport* h_rep = nullptr;    // host-mapped: the frame's last binning kernel writes its report here (gs_device.h); no per-frame copy
+    uint32_t* sticky = nullptr;   // device: [0] frames that overflowed, [1] fault, [2] largest I, [3] largest arena demand -- NOT in the
+                                  // per-frame memset (gs_frame_report)
+    size_t ctl_bytes_tight = 0;   // the part of the control block a tight frame polls: what its memset has to zero
     uint64_t max_I_seen = 0;      // largest instance count since GS_OPT_RESET_TIMING
     uint64_t truncated_frames = 0; // frames that overflowed the capacity and were NOT the frame gs_wait could re-render
     // outputs
@@ -215,13 +218,16 @@ static int32_t alloc_kv(gs_ctx* c, uint64_t capacity, uint64_t row_cap) {
     const size_t sort_sz = (size_t)std::max(c->passes, c->tile_passes) * gs_sort_tiles(capacity) * 256 * 4;
     const size_t rows_sz = c->tight_ok ? (size_t)gs_rows_sort_tiles(row_cap) * 256 * 4 : 0;
     const size_t depth_sz = ((size_t)c->T * 4 + 255) & ~(size_t)255;
-    c->ctl_bytes = ctl_sz + depth_sz + scan_sz + sort_sz + rows_sz;
+    // layout: control block | blend depth | row-sort status || scan status | instance-sort status: a tight frame zeroes the first
+    // three only (the instance sort's status alone is 27 MB at config B, and a tight frame never touches it)
+    c->ctl_bytes = ctl_sz + depth_sz + rows_sz + scan_sz + sort_sz;
+    c->ctl_bytes_tight = ctl_sz + depth_sz + rows_sz;
     HIP_TRY(hipMalloc(&c->ctl_mem, c->ctl_bytes));
     c->ctl = (GsControl*)c->ctl_mem;
     c->tile_depth = (uint32_t*)((char*)c->ctl_mem + ctl_sz);
-    c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz + depth_sz);
-    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz);
-    c->rows_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + scan_sz + sort_sz);
+    c->rows_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz);
+    c->scan_status = (unsigned long long*)((char*)c->ctl_mem + ctl_sz + depth_sz + rows_sz);
+    c->sort_status = (uint32_t*)((char*)c->ctl_mem + ctl_sz + depth_sz + rows_sz + scan_sz);
     c->capacity = capacity;
     c->row_cap = row_cap;
     c->frame.capacity = (uint32_t)capacity;
@@ -287,8 +293,8 @@ GS_EXPORT int32_t gs_create(const gs_config* cfg, gs_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->rowtot, 256 * 4));
     HIP_TRY(hipMalloc((void**)&c->sticky, 4 * 4));
     HIP_TRY(hipMemset(c->sticky, 0, 4 * 4));
-    HIP_TRY(hipHostMalloc((void**)&c->h_sticky, 4 * 4, hipHostMallocDefault));
-    memset(c->h_sticky, 0, 4 * 4);
+    HIP_TRY(hipHostMalloc((void**)&c->h_rep, sizeof(GsReport), hipHostMallocDefault));
+    memset(c->h_rep, 0, sizeof(GsReport));
     if (cfg->flags & GS_FLAG_TIMING) {
         for (auto& row : c->ev)
             for (auto& e : row) HIP_TRY(hipEventCreate(&e));
@@ -315,7 +321,7 @@ GS_EXPORT int32_t gs_destroy(gs_ctx* c) {
     hipFree(c->ranges); hipFree(c->rgba8); hipFree(c->rgbf); hipFree(c->d_pxb); hipFree(c->sticky); hipFree(c->blend_prof);
     hipFree(c->tileoff); hipFree(c->rowtot);
     if (c->h_ctl) hipHostFree(c->h_ctl);
-    if (c->h_sticky) hipHostFree(c->h_sticky);
+    if (c->h_rep) hipHostFree(c->h_rep);
     if (c->have_events)
         for (auto& row : c->ev)
             for (auto& e : row) hipEventDestroy(e);
@@ -454,7 +460,8 @@ static void mark_cb(void* p, int i) { mark((gs_ctx*)p, i); }
 static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8, bool tight) {
     const GsFrame& f = c->frame;
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, c->ctl_bytes, st));
+    HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, tight ? c->ctl_bytes_tight : c->ctl_bytes, st));
+    c->h_ctl_valid = false;
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);
     gs_preprocess_prepare(c->pre, c->scene, u, f, c->gdata, c->counts, tight, c->arena, c->rowptr, c->ctl, c->tight_nb);
@@ -470,7 +477,7 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
                         &c->ctl->num_visible, &c->ctl->num_slots, st);
         mark(c, 2);
         gs_launch_rows(c->arena, c->grec, c->chunk_table, c->rows_sorted, c->ctl, c->rows_status, (uint32_t)c->row_cap, c->M3, c->tileoff, c->rowtot, f, c->valsA,
-                       c->ranges, c->grid_persist / 4u, c->sticky, st, mark_cb, c);
+                       c->ranges, c->grid_persist / 4u, c->sticky, c->h_rep, st, mark_cb, c);
         c->keysS = nullptr;
         c->valsS = c->valsA;
         mark(c, 4);
@@ -509,8 +516,8 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
                            (uint32_t)c->capacity, c->tile_passes, c->tile_bits, keys16 ? 0 : 1, c->sort_status, c->grid_persist, /*have_hist=*/true,
                            nullptr, nullptr, st, &c->keysS, &c->valsS, keys16);
         mark(c, 4);
-        if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st);
-        else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, st); // streaming: 8 workgroups/CU
+        if (keys16) gs_launch_ranges16((const uint16_t*)c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, c->h_rep, st);
+        else gs_launch_ranges(c->keysS, c->ctl, (uint32_t)c->capacity, c->T, c->ranges, c->grid_persist * 2, c->sticky, c->h_rep, st); // streaming: 8 workgroups/CU
     }
     c->last_passes = tight ? 1u : (by_index ? c->passes : c->tile_passes);
     c->last_by_index = by_index;
@@ -525,9 +532,7 @@ static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ex
     c->blend_walkers = (uint32_t)walkers;
     mark(c, 6);
     if (c->debug_view) gs_launch_debug_view(c->ranges, f, c->debug_view, target, st); // developer views, after the timed stages
-    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(c->h_sticky, c->sticky, 4 * 4, hipMemcpyDeviceToHost, st));
-    return GS_OK;
+    return GS_OK; // (no copy back: the frame's report is in host-mapped memory when the stream has drained, gs_device.h GsReport)
 }
 
 static void drop_graph(gs_ctx* c) {
@@ -545,7 +550,7 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
         // canvas (18.5 M instances) 1.42 vs 1.50 ms, one of 8 slabs (1.9-2.6 M) 418-508 vs 455-566 us, one of 4 slabs 586-699 vs
         // 618-743 us per frame; below ~1 M instances both are launch-bound and the same.
         const uint64_t saved = c->passes > c->tile_passes ? c->passes - c->tile_passes : 0;
-        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_ctl->num_intersections >= 1000000ull);
+        c->index_order = !(c->have_frame && saved * (uint64_t)c->h_rep->num_intersections >= 1000000ull);
     } else {
         c->index_order = (c->emit_order == 1);
     }
@@ -629,17 +634,17 @@ static int32_t wait_one(gs_ctx* c) {
         c->pending = false;
         if (!c->have_frame) return GS_OK;
         // the sticky words cover EVERY frame enqueued since the last gs_wait (the control block only the last one)
-        const uint32_t over_frames = c->h_sticky[0], fault_any = c->h_sticky[1];
-        const uint64_t max_I = c->h_sticky[2], max_rows = c->h_sticky[3];
+        const uint32_t over_frames = c->h_rep->sticky[0], fault_any = c->h_rep->sticky[1];
+        const uint64_t max_I = c->h_rep->sticky[2], max_rows = c->h_rep->sticky[3];
         if (over_frames || fault_any || max_I || max_rows) HIP_TRY(hipMemset(c->sticky, 0, 4 * 4)); // stream is idle
-        c->h_sticky[0] = c->h_sticky[1] = c->h_sticky[2] = c->h_sticky[3] = 0;
+        c->h_rep->sticky[0] = c->h_rep->sticky[1] = c->h_rep->sticky[2] = c->h_rep->sticky[3] = 0;
         if (max_I > c->max_I_seen) c->max_I_seen = max_I;
-        if (fault_any || c->h_ctl->fault) return fail(GS_ERR_DEVICE_FAULT, "a look-back spin exceeded its bound (fault word set)");
-        const uint64_t I = c->h_ctl->num_intersections;
+        if (fault_any || c->h_rep->fault) return fail(GS_ERR_DEVICE_FAULT, "a look-back spin exceeded its bound (fault word set)");
+        const uint64_t I = c->h_rep->num_intersections;
         uint64_t rows_last = 0; // arena slots the last frame asked for: 16 shards as large as its fullest one
         if (c->last_tight)
-            for (int k = 0; k < 16; ++k) rows_last = std::max<uint64_t>(rows_last, (uint64_t)c->h_ctl->row_cursor[k] * 16);
-        const bool last_over = I > c->capacity || c->h_ctl->overflow;
+            for (int k = 0; k < 16; ++k) rows_last = std::max<uint64_t>(rows_last, (uint64_t)c->h_rep->row_cursor[k] * 16);
+        const bool last_over = I > c->capacity || c->h_rep->overflow;
         if (attempt == 0 && over_frames > (last_over ? 1u : 0u)) dropped = over_frames - (last_over ? 1u : 0u);
         const uint64_t need = std::max<uint64_t>(I, max_I), need_rows = std::max<uint64_t>(rows_last, max_rows);
         if (!last_over && need <= c->capacity && need_rows <= c->row_cap) break;
@@ -797,7 +802,7 @@ GS_EXPORT int32_t gs_slab_width(gs_ctx* c, uint32_t* px_begin, uint32_t* px_widt
 }
 
 static int32_t tap(gs_ctx* c, int32_t which, void** ptr, uint64_t* bytes) {
-    const uint64_t I = std::min<uint64_t>(c->h_ctl->num_intersections, c->capacity);
+    const uint64_t I = std::min<uint64_t>(c->h_rep->num_intersections, c->capacity);
     const uint64_t px = (uint64_t)c->frame.slab_w * c->frame.height;
     switch (which) {
     case GS_BUF_TILE_COUNTS: *ptr = c->counts; *bytes = (uint64_t)c->n * 4; return GS_OK;
@@ -847,7 +852,7 @@ GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t s
     void* p = nullptr;
     uint64_t bytes = 0;
     if (which == GS_BUF_BLOCK_MASKS && !c->last_tight) { // the reference's binning: the blend tests every block of the tile itself
-        bytes = std::min<uint64_t>(c->h_ctl->num_intersections, c->capacity) * 4;
+        bytes = std::min<uint64_t>(c->h_rep->num_intersections, c->capacity) * 4;
         if (written) *written = bytes;
         if (!dst) return GS_OK;
         if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
@@ -862,7 +867,7 @@ GS_EXPORT int32_t gs_read_buffer(gs_ctx* c, int32_t which, void* dst, uint64_t s
         if (written) *written = bytes;
         if (!dst) return GS_OK;
         if (size < bytes) return fail(GS_ERR_INVALID_ARGUMENT, "gs_read_buffer: need %llu bytes, got %llu", (unsigned long long)bytes, (unsigned long long)size);
-        const uint64_t I = std::min<uint64_t>(c->h_ctl->num_intersections, c->capacity);
+        const uint64_t I = std::min<uint64_t>(c->h_rep->num_intersections, c->capacity);
         std::vector<uint32_t> v(I);
         if (I) HIP_TRY(hipMemcpy(v.data(), c->valsS, I * 4, hipMemcpyDeviceToHost));
         uint32_t* w = (uint32_t*)dst;
@@ -928,10 +933,15 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* root, gs_stats* out) {
     for (gs_ctx* s : root->shadows) out->frames += s->frames;
     out->depth_ordered = (c->have_frame && !c->last_by_index) ? 1u : 0u;
     if (c->have_frame) {
-        out->num_visible = c->h_ctl->num_visible;
-        out->num_intersections = c->h_ctl->num_intersections;
+        if (!c->h_ctl_valid) { // the blend's counters live in the control block: fetched when somebody asks
+            HIP_TRY(hipSetDevice(c->cfg.device));
+            HIP_TRY(hipMemcpy(c->h_ctl, c->ctl, offsetof(GsControl, hist), hipMemcpyDeviceToHost));
+            c->h_ctl_valid = true;
+        }
+        out->num_visible = c->h_rep->num_visible;
+        out->num_intersections = c->h_rep->num_intersections;
         out->capacity = c->capacity;
-        out->max_intersections_seen = std::max<uint64_t>(c->max_I_seen, c->h_ctl->num_intersections);
+        out->max_intersections_seen = std::max<uint64_t>(c->max_I_seen, c->h_rep->num_intersections);
         out->truncated_frames = root->truncated_frames;
         for (gs_ctx* s : root->shadows) out->truncated_frames += s->truncated_frames;
         out->frames_in_flight = (uint32_t)root->shadows.size() + 1u;
@@ -940,8 +950,8 @@ GS_EXPORT int32_t gs_get_stats(gs_ctx* root, gs_stats* out) {
         out->tight_binning = c->last_tight ? 1u : 0u;
         out->row_capacity = c->row_cap;
         if (c->last_tight) {
-            out->num_row_items = c->h_ctl->num_items;
-            out->num_row_slots = c->h_ctl->num_slots;
+            out->num_row_items = c->h_rep->num_items;
+            out->num_row_slots = c->h_rep->num_slots;
         }
         for (int k = 0; k < 64; ++k) out->num_processed += c->h_ctl->num_processed[k];
         if (c->blend_walkers >= 4) { // 8x8-block walkers (4 per 16-tile, 16 per 32-tile): sum over tiles of the deepest walker

@@ -377,17 +377,14 @@ __device__ __forceinline__ void ranges_boundary(uint32_t j, uint32_t lo, uint32_
 // sticky (optional): words that survive the per-frame memset of the control block.  Every frame folds its overflow / fault
 // flags and its instance count into them, so gs_wait also learns about frames that were enqueued BEFORE the last one
 // ([0] frames that overflowed the capacity, [1] a bounded spin gave up, [2] largest instance count seen).
-__device__ __forceinline__ void fold_sticky(const GsControl* ctl, uint32_t capacity, uint32_t* sticky) {
-    if (!sticky || blockIdx.x != 0 || threadIdx.x != 0) return;
-    const uint32_t I = ctl->num_intersections;
-    if (ctl->overflow || I > capacity) atomicAdd(&sticky[0], 1u);
-    if (ctl->fault) atomicOr(&sticky[1], 1u);
-    atomicMax(&sticky[2], I);
+__device__ __forceinline__ void fold_sticky(const GsControl* ctl, uint32_t capacity, uint32_t* sticky, GsReport* rep) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    gs_frame_report(ctl, ctl->num_intersections, 0u, capacity, sticky, rep);
 }
 
 __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restrict__ keys, const GsControl* ctl, uint32_t capacity,
-                                                         uint32_t T, uint32_t* __restrict__ ranges, uint32_t* sticky) {
-    fold_sticky(ctl, capacity, sticky);
+                                                         uint32_t T, uint32_t* __restrict__ ranges, uint32_t* sticky, GsReport* rep) {
+    fold_sticky(ctl, capacity, sticky, rep);
     uint32_t I = ctl->num_intersections;
     if (I > capacity) I = capacity;
     const uint64_t nchunks = (uint64_t)I / 4 + 1; // chunk c covers boundaries 4c .. 4c+3 (those <= I)
@@ -416,8 +413,8 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const uint32_t* __restri
 
 // The same over sorted 16-bit tile ids (depth-ordered pipeline): eight per 16-byte load.
 __global__ __launch_bounds__(256) void gs_ranges16_kernel(const uint16_t* __restrict__ tiles, const GsControl* ctl, uint32_t capacity,
-                                                           uint32_t T, uint32_t* __restrict__ ranges, uint32_t* sticky) {
-    fold_sticky(ctl, capacity, sticky);
+                                                           uint32_t T, uint32_t* __restrict__ ranges, uint32_t* sticky, GsReport* rep) {
+    fold_sticky(ctl, capacity, sticky, rep);
     uint32_t I = ctl->num_intersections;
     if (I > capacity) I = capacity;
     const uint64_t nchunks = (uint64_t)I / 8 + 1; // chunk c covers boundaries 8c .. 8c+7 (those <= I)
@@ -458,8 +455,8 @@ __global__ __launch_bounds__(256) void gs_rebuild_keys_kernel(const uint16_t* __
 
 // ---- host launchers --------------------------------------------------------------------------------
 void gs_launch_ranges16(const uint16_t* tiles, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                        uint32_t* sticky, hipStream_t st) {
-    hipLaunchKernelGGL(gs_ranges16_kernel, dim3(grid), dim3(256), 0, st, tiles, ctl, capacity, T, ranges, sticky);
+                        uint32_t* sticky, GsReport* rep, hipStream_t st) {
+    hipLaunchKernelGGL(gs_ranges16_kernel, dim3(grid), dim3(256), 0, st, tiles, ctl, capacity, T, ranges, sticky, rep);
 }
 void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n, uint32_t id_mask,
                             uint32_t* keys, hipStream_t st) {
@@ -487,6 +484,6 @@ void gs_launch_emit(const void* gdata, const uint32_t* counts, const uint32_t* o
     hipLaunchKernelGGL(gs_emit_kernel, dim3(blocks), dim3(256), 0, st, (const uint4*)gdata, counts, offsets, perm, n_dev, f, keys, values, ctl);
 }
 void gs_launch_ranges(const uint32_t* keys, const GsControl* ctl, uint32_t capacity, uint32_t T, uint32_t* ranges, uint32_t grid,
-                      uint32_t* sticky, hipStream_t st) {
-    hipLaunchKernelGGL(gs_ranges_kernel, dim3(grid), dim3(256), 0, st, keys, ctl, capacity, T, ranges, sticky);
+                      uint32_t* sticky, GsReport* rep, hipStream_t st) {
+    hipLaunchKernelGGL(gs_ranges_kernel, dim3(grid), dim3(256), 0, st, keys, ctl, capacity, T, ranges, sticky, rep);
 }

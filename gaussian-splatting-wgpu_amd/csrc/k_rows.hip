@@ -413,7 +413,7 @@ struct ExpandShared {
 __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __restrict__ rows, GsControl* ctl, const uint32_t* __restrict__ M3,
                                                              const uint32_t* __restrict__ tileoff, const uint32_t* __restrict__ rowtot, GsFrame f,
                                                              uint32_t* __restrict__ values, uint32_t* __restrict__ ranges, uint32_t chunk_cap,
-                                                             uint32_t* sticky) {
+                                                             uint32_t* sticky, GsReport* rep) {
     __shared__ ExpandShared S;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -439,21 +439,12 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
         if (tid == 255u) S.rbase[256] = (b + incl) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(b + incl);
         __syncthreads();
     }
-    if (blockIdx.x == 0 && tid == 0) { // the frame's instance count; overflow / fault / size folded into the sticky words
+    if (blockIdx.x == 0 && tid == 0) { // the frame's instance count; its flags and sizes go to the sticky words and the host's report
         const uint32_t I = S.rbase[256];
         ctl->num_intersections = I;
         ctl->num_items = S.T.ibase[256];
-        const bool over = I > f.capacity || ctl->overflow;
         if (I > f.capacity) ctl->overflow = 1u;
-        if (sticky) {
-            uint32_t need = 0; // arena slots this frame would have needed: 16 shards as large as the fullest one
-            for (int k = 0; k < 16; ++k) need = ctl->row_cursor[k] > need ? ctl->row_cursor[k] : need;
-            need = need > 0x07FFFFFFu ? 0x7FFFFFFFu : need * 16u;
-            if (over) atomicAdd(&sticky[0], 1u);
-            if (ctl->fault) atomicOr(&sticky[1], 1u);
-            atomicMax(&sticky[2], I);
-            atomicMax(&sticky[3], need);
-        }
+        gs_frame_report(ctl, I, S.T.ibase[256], f.capacity, sticky, rep);
     }
     // ranges[t] = end of tile t's list (compute_ranges.wgsl:5-29): workgroup r writes tile row r
     for (uint32_t r = blockIdx.x; r < f.nty; r += gridDim.x) {
@@ -674,7 +665,7 @@ uint32_t gs_rows_chunks(uint64_t row_cap) { return (uint32_t)(row_cap / RB_CH + 
 // cus: compute units (grids are sized by residency: three 8-wave workgroups of the sort, five of the expansion, eight of the count fit a CU)
 void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chunk_table, uint32_t* rows_sorted, GsControl* ctl, uint32_t* sort_status, uint32_t row_cap,
                     uint32_t* M3, uint32_t* tileoff, uint32_t* rowtot, const GsFrame& f, uint32_t* values, uint32_t* ranges, uint32_t cus,
-                    uint32_t* sticky, hipStream_t st, void (*mark)(void*, int), void* mark_arg) {
+                    uint32_t* sticky, GsReport* rep, hipStream_t st, void (*mark)(void*, int), void* mark_arg) {
     const uint32_t chunk_cap = gs_rows_chunks(row_cap);
     if (!cus) cus = 1;
     hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
@@ -683,7 +674,7 @@ void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chu
     hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * 8u), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
     hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap);
     hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * 6u), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
-                       (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, sticky);
+                       (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, sticky, rep);
 }
 void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,
                                  uint32_t* keys, hipStream_t st) {
