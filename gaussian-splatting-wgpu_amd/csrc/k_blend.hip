@@ -261,6 +261,20 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
 // it gathers: entries that cannot touch its pixels cost one id read and nothing else (no record gather, no cull
 // arithmetic).  At tile 16 the bit is per 8x8 block, i.e. exactly this walker's pixels, so the closed-form cull below is
 // skipped altogether; at tile 32 the bit is per 16x16 quadrant and the cull still runs on what the bit lets through.
+#ifdef GS_PROFILING
+// PROFILING BUILD ONLY: footprint of the evaluations -- [0] evaluations, [1] lanes with alpha >= 1/255, [2] 4x4 pixel quads (of the
+// block's four) holding such a lane, [3] evaluations with none; 256 copies 128 bytes apart
+__device__ unsigned long long gs_blend_foot[256][16];
+extern "C" __attribute__((visibility("default"))) int gs_prof_blend_footprint(unsigned long long* out4, int reset) {
+    static unsigned long long h[256][16];
+    if (out4) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_blend_foot), sizeof(h)) != hipSuccess) return -1;
+        for (int k = 0; k < 4; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
+    }
+    if (reset) { for (auto& r : h) for (auto& v : r) v = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(gs_blend_foot), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 typedef uint32_t gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t gs_u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t gs_u32x4 __attribute__((ext_vector_type(4)));
@@ -314,6 +328,9 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     bool done = outside;
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     uint32_t staged = 0, evaluated = 0;
+#ifdef GS_PROFILING
+    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0;
+#endif
 
     // the three pieces of a record a lane fetches (uv | conic | colour, opacity), as native vectors: each is ONE register tuple
     // from the load to the asm pin below, so nothing has to be copied (and waited for) in between
@@ -443,6 +460,15 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     const float pw = __builtin_fmaf(dx, u, tt.y); // power * log2(e) + log2(op)
                     const float alpha = __builtin_fminf(0.99f, __builtin_amdgcn_exp2f(pw));
                     const float test = __builtin_fmaf(-T, alpha, T);
+#ifdef GS_PROFILING
+                    if (dbg & 32u) {
+                        const unsigned long long km = __ballot(alpha >= c255);
+                        const unsigned long long q0 = 0x000000000F0F0F0Full; // pixel (x, y) = (lane & 7, lane >> 3): quad (x >> 2, y >> 2)
+                        fp_lanes += (uint32_t)__popcll(km);
+                        fp_quads += (uint32_t)((km & q0) != 0) + (uint32_t)((km & (q0 << 4)) != 0) + (uint32_t)((km & (q0 << 32)) != 0) + (uint32_t)((km & (q0 << 36)) != 0);
+                        fp_none += (uint32_t)(km == 0);
+                    }
+#endif
                     if (CHECKED) {
                         bool keep = (alpha >= c255) && (test >= 0.0001f);
                         keep = keep && (pw <= bl.y); // power <= 0
@@ -493,6 +519,11 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     if (lane == 0 && staged) atomicMax(&tile_depth[lin], staged);
     if (lane == 0 && evaluated) atomicAdd(&ctl->num_evaluated[(b + 1u) & 63u], (unsigned long long)evaluated);
 #ifdef GS_PROFILING
+    if ((dbg & 32u) && lane == 0) {
+        unsigned long long* fp = gs_blend_foot[b & 255u];
+        atomicAdd(&fp[0], (unsigned long long)evaluated); atomicAdd(&fp[1], (unsigned long long)fp_lanes);
+        atomicAdd(&fp[2], (unsigned long long)fp_quads); atomicAdd(&fp[3], (unsigned long long)fp_none);
+    }
     if (prof && lane == 0) {
         prof[b * 4u + 0u] = t_start;
         prof[b * 4u + 1u] = (uint32_t)__builtin_amdgcn_s_memrealtime();

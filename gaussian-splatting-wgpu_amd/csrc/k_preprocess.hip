@@ -199,6 +199,26 @@ __device__ __forceinline__ bool in_frustum_slab(const GsUniforms& u, const GsFra
     return (reach || alias) || !(rb == rb);
 }
 
+#ifdef GS_PROFILING
+// PROFILING BUILD ONLY (tools/pre_profile.py): clock cycles the waves of the tight projection spend in its phases, summed over the
+// waves of a launch ([0] cull, [1] projection arithmetic, [2] slot scan + cursor bump, [3] row-item loop, [4] colour + record,
+// [5] waves).  256 copies, 128 bytes apart, picked by workgroup: 24 000 waves adding to one line would take longer than the kernel.
+__device__ unsigned long long gs_pre_prof[256][16];
+extern "C" __attribute__((visibility("default"))) int gs_prof_preprocess(unsigned long long* out8, int reset) {
+    static unsigned long long h[256][16];
+    if (out8) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_pre_prof), sizeof(h)) != hipSuccess) return -1;
+        for (int k = 0; k < 8; ++k) { out8[k] = 0; for (int c = 0; c < 256; ++c) out8[k] += h[c][k]; }
+    }
+    if (reset) { for (auto& r : h) for (auto& v : r) v = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(gs_pre_prof), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
+// (wave-uniform by construction: readfirstlane keeps the accumulators in scalar registers, the kernel's vector budget is untouched)
+#define PRE_STAMP(k) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime()); \
+                          pacc[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pacc[k] + (t_ - tprev))); tprev = t_; } while (0)
+#else
+#define PRE_STAMP(k) do { } while (0)
+#endif
 #define PRE_G 512 // gaussians per cull chunk
 #ifndef PRE_WAVES
 #define PRE_WAVES 4 // waves per SIMD the register allocator must leave room for
@@ -237,6 +257,10 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
     const uint32_t bid = blockIdx.x;
     const uint32_t base = bid * (PRE_G * NB);
     if (TIGHT) s_rowhist[tid] = 0u;
+#ifdef GS_PROFILING
+    uint32_t pacc[5] = {0, 0, 0, 0, 0};
+    uint32_t tprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());
+#endif
 
     // ---- phase 1: in_frustum (:108-125) on the position planes, survivors compacted ----
     uint32_t nvis = 0;
@@ -306,6 +330,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         __syncthreads();
     }
 
+    PRE_STAMP(0);
     // ---- phases 2 and 3: one survivor per lane ----
     const uint32_t trips = (nvis + 255u) / 256u;
     const uint32_t ts_ = f.tile_size, sub = ts_ >= 16u ? ts_ / 2u : ts_, ns = ts_ / sub;
@@ -413,6 +438,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
                 count = 0u;
             }
             s_tcnt[tid] = 0u;
+            PRE_STAMP(1);
             const uint32_t rincl = wave_incl_scan(nslots, lane);
             const uint32_t Rw = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63); // slots of this wave's survivors
             const uint32_t myrp = rincl - nslots;
@@ -432,6 +458,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             __syncthreads();
             const uint32_t abase = shard * shard_cap + s_misc[2] + wbase;
             const bool ok = s_misc[3] != 0u;
+            PRE_STAMP(2);
             uint32_t jcarry = 0u; // owner (+1) of the slot just before the batch
             for (uint32_t rb0 = 0; rb0 < Rw; rb0 += 64u) {
                 // owner of a slot = the survivor whose slots [myrp, myrp + nslots) hold it: every survivor with slots marks the batch
@@ -472,6 +499,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (count) count = ok ? s_tcnt[tid] : 0u;
             rowptr = abase + myrp;
+            PRE_STAMP(3);
             if (!active) continue;
         }
         // low 22 bits: tile count (TIGHT: row-item slots); high 10: the key's depth bucket, u32(min(50*depth, 999)) (write_tile_ids.wgsl:31)
@@ -491,6 +519,14 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         o4[2] = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[1]), __float_as_uint(col[2]), __float_as_uint(opacity));
         o4[3] = make_uint4(rminx, rminy, rmaxx, rmaxy);
     }
+    PRE_STAMP(4);
+#ifdef GS_PROFILING
+    if (TIGHT && lane == 0) {
+        unsigned long long* pp = gs_pre_prof[(bid * 4u + w) & 255u];
+        for (int k = 0; k < 5; ++k) atomicAdd(&pp[k], (unsigned long long)pacc[k]);
+        atomicAdd(&pp[5], 1ull);
+    }
+#endif
     if (TIGHT) { // the workgroup's items per tile row -> the row sort's digit histogram
         __syncthreads();
         const uint32_t c = s_rowhist[tid];
