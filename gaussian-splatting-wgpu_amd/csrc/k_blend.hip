@@ -287,14 +287,15 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
 #ifdef GS_PROFILING // (build.py --profiling; GS_OPT_BLEND_ABLATION bit 16): start / end stamp (100 MHz), evaluated and staged entries per walker
     const uint32_t t_start = prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
 #endif
-    __shared__ float4 sP0[64];                 // EXACT: gx gy - -      fused: gx, conic.x', r, g
+    __shared__ float4 sP0[64];                 // EXACT: gx gy - -      fused: conic.x', 0.99 r, 0.99 g, 0.99 b
     __shared__ float4 sP1[EXACT ? 64 : 1];     // EXACT: conic
     __shared__ float4 sP2[EXACT ? 64 : 1];     // EXACT: r g b opacity
-    __shared__ float2 sB[EXACT ? 1 : 64];      // fused: b, log2(opacity)
-    // fused: the part of the exponent that depends on the pixel ROW only -- (conic.y' dy, conic.z' dy^2 + log2 opacity) for the 8
-    // rows of the block, tabulated by the lane that parks the entry.  dy takes 8 values in an 8x8 block: evaluating those two
-    // terms per (entry, pixel) spent 4 of the loop's 17 VALU instructions on 8-fold redundant work.  Rows are 65 slots apart:
-    // the 8 rows of a slot then sit in 8 different bank pairs (ds_read_b64).
+    __shared__ float sL[EXACT ? 1 : 64];       // fused: log2(opacity / 0.99) (only the checked walk reads it)
+    // fused: the exponent of a pixel as a polynomial in its COLUMN inside the block, xl = 0..7:
+    //     log2(alpha / 0.99) = C xl^2 + B_r xl + A_r,   C = conic.x' per entry, (B_r, A_r) per entry and pixel ROW r of the block,
+    // tabulated by the lane that parks the entry (4 instructions per row).  The loop evaluates it with two fmas and no
+    // subtraction; round 3's first table (conic.y' dy, conic.z' dy^2 + log2 op per row) still needed dx = gx - px and a third
+    // read per entry.  Rows are 65 slots apart: the 8 rows of a slot then sit in 8 different bank pairs (ds_read_b64).
     __shared__ float2 sT[EXACT ? 1 : 8 * 65];
     const uint32_t lane = threadIdx.x;
     const uint32_t slab_tx = f.col1 - f.col0;
@@ -409,13 +410,20 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 sP1[slot] = make_float4(cx, cy, cz, 0.0f);
                 sP2[slot] = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), op);
             } else {
-                const float hx = (-0.5f * L) * cx, hy = (-L) * cy, hz = (-0.5f * L) * cz, lop = __builtin_amdgcn_logf(op);
-                sP0[slot] = make_float4(gxp, hx, __uint_as_float(r2.x), __uint_as_float(r2.y));
-                sB[slot] = make_float2(__uint_as_float(r2.z), lop);
+                // with d = gx - bx0 (block-relative centre), dy = gy - (by0 + r):
+                //   hx (d - xl)^2 + hy dy (d - xl) + hz dy^2 + lop'  =  hx xl^2 + (-2 hx d - hy dy) xl + (hx d^2 + hy d dy + hz dy^2 + lop')
+                // lop' = log2(op / 0.99): the loop computes e = min(1, alpha / 0.99) with the exp's clamp modifier, and 0.99 rides in
+                // the colours and the constants (alpha = min(0.99, op exp(power)), compute_tiles.wgsl:61)
+                const float hx = (-0.5f * L) * cx, hy = (-L) * cy, hz = (-0.5f * L) * cz;
+                const float lop = __builtin_amdgcn_logf(op) + 0.014499569695115089f; // + log2(1 / 0.99)
+                const float d = gxp - bx0f;
+                const float b0 = (-2.0f * hx) * d, a1 = hy * d, a0 = __builtin_fmaf(hx * d, d, lop);
+                sP0[slot] = make_float4(hx, 0.99f * __uint_as_float(r2.x), 0.99f * __uint_as_float(r2.y), 0.99f * __uint_as_float(r2.z));
+                sL[slot] = lop;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { // the same operations, in the same order, as the per-pixel form they replace
+                for (int r = 0; r < 8; ++r) {
                     const float dy = gyp - (by0f + (float)r);
-                    sT[r * 65 + slot] = make_float2(hy * dy, __builtin_fmaf(hz * dy, dy, lop));
+                    sT[r * 65 + slot] = make_float2(__builtin_fmaf(-hy, dy, b0), __builtin_fmaf(dy, __builtin_fmaf(dy, hz, a1), a0));
                 }
             }
         }
@@ -434,12 +442,13 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         // a batch that holds a survivor with a non-positive-definite conic (never produced by the projection's +0.3
         // low-pass; NaN records land here too).
         const uint32_t trow = (lane >> 3) * 65u;
+        const float xlf = (float)(lane & 7u);
         auto walk = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
             auto one = [&](uint32_t e) {
                 const float4 p0 = sP0[e];
-                const float dx = p0.x - pxf;
                 if (EXACT) {
+                    const float dx = p0.x - pxf;
                     const float4 p1 = sP1[e];
                     const float dy = p0.y - pyf;
                     const float4 p2v = sP2[e];
@@ -453,16 +462,14 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     cb += cond * p2v.z * alpha * T;
                     T = cond * test + (1.0f - cond) * T;
                 } else {
-                    const float2 bl = sB[e];
-                    const float colb = bl.x;
-                    const float2 tt = sT[trow + e];            // this pixel row's (conic.y' dy, conic.z' dy^2 + log2 op)
-                    const float u = __builtin_fmaf(p0.y, dx, tt.x);
-                    const float pw = __builtin_fmaf(dx, u, tt.y); // power * log2(e) + log2(op)
-                    const float alpha = __builtin_fminf(0.99f, __builtin_amdgcn_exp2f(pw));
-                    const float test = __builtin_fmaf(-T, alpha, T);
+                    const float2 tt = sT[trow + e];            // this pixel row's (B_r, A_r)
+                    const float pw = __builtin_fmaf(xlf, __builtin_fmaf(xlf, p0.x, tt.x), tt.y); // log2(alpha / 0.99) before the clamp
+                    float ea; // min(1, alpha / 0.99): v_exp_f32 with the clamp modifier (one instruction; a v_min on alpha was a second)
+                    asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(ea) : "v"(pw));
+                    const float k1 = (float)(1.0 / 255.0 / 0.99); // alpha >= 1/255  <=>  ea >= 1/(255 * 0.99)
 #ifdef GS_PROFILING
                     if (dbg & 32u) {
-                        const unsigned long long km = __ballot(alpha >= c255);
+                        const unsigned long long km = __ballot(ea >= k1);
                         const unsigned long long q0 = 0x000000000F0F0F0Full; // pixel (x, y) = (lane & 7, lane >> 3): quad (x >> 2, y >> 2)
                         fp_lanes += (uint32_t)__popcll(km);
                         fp_quads += (uint32_t)((km & q0) != 0) + (uint32_t)((km & (q0 << 4)) != 0) + (uint32_t)((km & (q0 << 32)) != 0) + (uint32_t)((km & (q0 << 36)) != 0);
@@ -470,34 +477,35 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     }
 #endif
                     if (CHECKED) {
-                        bool keep = (alpha >= c255) && (test >= 0.0001f);
-                        keep = keep && (pw <= bl.y); // power <= 0
-                        const float wgt = (keep ? alpha : 0.0f) * T;
-                        cr = __builtin_fmaf(p0.z, wgt, cr);
-                        cg = __builtin_fmaf(p0.w, wgt, cg);
-                        cb = __builtin_fmaf(colb, wgt, cb);
+                        const float wgt = T * ea;                   // T alpha / 0.99 (the colours carry the 0.99)
+                        const float test = __builtin_fmaf(wgt, -0.99f, T);
+                        bool keep = (ea >= k1) && (test >= 0.0001f);
+                        keep = keep && (pw <= sL[e]); // power <= 0
+                        const float wk = keep ? wgt : 0.0f;
+                        cr = __builtin_fmaf(p0.y, wk, cr);
+                        cg = __builtin_fmaf(p0.z, wk, cg);
+                        cb = __builtin_fmaf(p0.w, wk, cb);
                         T = keep ? test : T;
                     } else {
-                        // The keep/skip decision as an exec mask instead of two selects: the two compares narrow exec, the weight,
-                        // the three accumulations and the new T are written under it, exec is restored.  7 VALU where the
-                        // compiler's form (2 compares, 2 v_cndmask, 1 mul, 3 fma) takes 8 -- and this loop runs at the VALU
-                        // issue rate (4.4e8 wave-instructions per frame on 1024 SIMDs at 4 cycles each = the kernel's time).
-                        // Same operations on the kept lanes, nothing on the others: the frame does not change by a bit.
-                        float wgt;
+                        // The keep/skip decision as an exec mask instead of two selects: the two compares narrow exec, the three
+                        // accumulations and the new T are written under it, exec is restored.  11 VALU per evaluation in all (2 fma,
+                        // exp, mul, fma, 2 cmpx, mov, 3 fmac) -- and this loop runs at the VALU issue rate, two thirds of the frame's
+                        // vector instructions are issued here.  Same operations on the kept lanes, nothing on the others.
+                        float wgt, test;
                         unsigned long long save;
                         asm(
+                            "v_mul_f32_e32 %[wgt], %[T], %[ea]\n\t"
+                            "v_fma_f32 %[test], %[wgt], %[m99], %[T]\n\t"
                             "s_mov_b64 %[save], exec\n\t"
-                            "v_cmpx_le_f32_e32 vcc, %[c255], %[alpha]\n\t"
+                            "v_cmpx_le_f32_e32 vcc, %[k1], %[ea]\n\t"
                             "v_cmpx_le_f32_e32 vcc, %[thr], %[test]\n\t"
-                            "v_mul_f32_e32 %[wgt], %[T], %[alpha]\n\t"
                             "v_mov_b32_e32 %[T], %[test]\n\t"
                             "v_fmac_f32_e32 %[cr], %[c0], %[wgt]\n\t"
                             "v_fmac_f32_e32 %[cg], %[c1], %[wgt]\n\t"
                             "v_fmac_f32_e32 %[cb], %[c2], %[wgt]\n\t"
                             "s_mov_b64 exec, %[save]"
-                            : [save] "=&s"(save), [wgt] "=&v"(wgt), [T] "+v"(T), [cr] "+v"(cr), [cg] "+v"(cg), [cb] "+v"(cb)
-                            : [c255] "s"(c255), [thr] "s"(0.0001f), [alpha] "v"(alpha), [test] "v"(test), [c0] "v"(p0.z), [c1] "v"(p0.w),
-                              [c2] "v"(colb)
+                            : [save] "=&s"(save), [wgt] "=&v"(wgt), [test] "=&v"(test), [T] "+v"(T), [cr] "+v"(cr), [cg] "+v"(cg), [cb] "+v"(cb)
+                            : [k1] "s"(k1), [thr] "s"(0.0001f), [m99] "s"(-0.99f), [ea] "v"(ea), [c0] "v"(p0.y), [c1] "v"(p0.z), [c2] "v"(p0.w)
                             : "vcc");
                     }
                 }
