@@ -17,6 +17,7 @@ ARCH = "gfx950"
 # loads): projection 282 -> 243 us, blend 738 -> 712 us with the flag (profiles/README.md).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+FILE_FLAGS = {}  # per-file flags (none at present)
 SOURCES = ["k_preprocess.hip", "k_binning.hip", "k_gsort.hip", "k_rows.hip", "k_sort.hip", "k_blend.hip", "gs_runtime.hip"]
 
 
@@ -40,7 +41,7 @@ def build(force=False, verbose=False, profiling=False):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(HERE, src)
         if force or _stale(obj, [path] + headers):
-            cmd = [HIPCC] + FLAGS + (["-DGS_PROFILING"] if profiling else []) + ["-c", path, "-o", obj]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (["-DGS_PROFILING"] if profiling else []) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

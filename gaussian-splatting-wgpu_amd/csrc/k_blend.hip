@@ -287,16 +287,28 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
 #ifdef GS_PROFILING // (build.py --profiling; GS_OPT_BLEND_ABLATION bit 16): start / end stamp (100 MHz), evaluated and staged entries per walker
     const uint32_t t_start = prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
 #endif
-    __shared__ float4 sP0[64];                 // EXACT: gx gy - -      fused: conic.x', 0.99 r, 0.99 g, 0.99 b
-    __shared__ float4 sP1[EXACT ? 64 : 1];     // EXACT: conic
-    __shared__ float4 sP2[EXACT ? 64 : 1];     // EXACT: r g b opacity
-    __shared__ float sL[EXACT ? 1 : 64];       // fused: log2(opacity / 0.99) (only the checked walk reads it)
+    // EXACT: sP0 gx gy - - | sP1 conic | sP2 r g b opacity.   fused: sP0 conic.x', 0.99 r, 0.99 g, 0.99 b | sL log2(opacity / 0.99)
+    // (only the checked walk reads it).  sQ: ring of the value words whose mask bit is this walker's, in list order.
     // fused: the exponent of a pixel as a polynomial in its COLUMN inside the block, xl = 0..7:
     //     log2(alpha / 0.99) = C xl^2 + B_r xl + A_r,   C = conic.x' per entry, (B_r, A_r) per entry and pixel ROW r of the block,
     // tabulated by the lane that parks the entry (4 instructions per row).  The loop evaluates it with two fmas and no
     // subtraction; round 3's first table (conic.y' dy, conic.z' dy^2 + log2 op per row) still needed dx = gx - px and a third
     // read per entry.  Rows are 65 slots apart: the 8 rows of a slot then sit in 8 different bank pairs (ds_read_b64).
-    __shared__ float2 sT[EXACT ? 1 : 8 * 65];
+#ifndef GS_L_OFF_T
+#define GS_L_OFF_T 0
+#define GS_L_OFF_Q 4160
+#define GS_L_OFF_P 5184
+#define GS_L_OFF_L 6208
+#define GS_L_TOTAL 6464
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char lds_x[EXACT ? 4096 : 16];         // EXACT: sP0 | sP1 | sP2 | sQ
+    __shared__ __attribute__((aligned(16))) unsigned char lds_f[EXACT ? 16 : GS_L_TOTAL];   // fused: placed by hand (the offsets matter: see gs_launch_blend)
+    float4* const sP0 = reinterpret_cast<float4*>(EXACT ? lds_x : lds_f + GS_L_OFF_P);
+    float4* const sP1 = reinterpret_cast<float4*>(lds_x + (EXACT ? 1024 : 0));
+    float4* const sP2 = reinterpret_cast<float4*>(lds_x + (EXACT ? 2048 : 0));
+    uint32_t* const sQ = reinterpret_cast<uint32_t*>(EXACT ? lds_x + 3072 : lds_f + GS_L_OFF_Q);
+    float* const sL = reinterpret_cast<float*>(lds_f + (EXACT ? 0 : GS_L_OFF_L));
+    float2* const sT = reinterpret_cast<float2*>(lds_f + (EXACT ? 0 : GS_L_OFF_T));
     const uint32_t lane = threadIdx.x;
     const uint32_t slab_tx = f.col1 - f.col0;
     // Workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own L2.  XCD x owns the column strips
@@ -338,39 +350,75 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     gs_u32x2 r0 = {0u, 0u};
     gs_u32x3 r1 = {0u, 0u, 0u};
     gs_u32x4 r2 = {0u, 0u, 0u, 0u};
-    uint32_t gnext = 0, vcur = 0; // value words of the next / the current batch's entry of this lane
     // this walker's bit of the mask: its 8x8 block at tile 16, the 16x16 quadrant holding it at tile 32
     constexpr bool QCULL = !MASKED || TS == 32;
     const uint32_t mybit = GS_ID_BITS + (TS == 32 ? ((q / BPR) / 2u) * 2u + ((q % BPR) / 2u) : q);
-    // Both loads are UNCONDITIONAL (a lane without work reads the list's last id / record 0, lines every wave shares): an
-    // exec-masked load leaves the compiler merging old and new registers right behind the load, i.e. waiting for it at
-    // once, and the prefetch below would be a prefetch in name only (it was, until round 2).
-    auto fetch_id = [&](uint32_t bb) {
-        const uint32_t i = bb + lane;
-        gnext = values[i < end ? i : end - 1u];
+    // The ID STREAM.  A walker's bit is set in about three of eight entries of its tile's list (tile 16).  Round 2 parked the
+    // survivors of every 64 list entries -- 24 on average -- so the per-batch work (the row tables: 4 instructions and an LDS
+    // store per pixel row, by the survivor's lane) ran on 37 % of the lanes and was 18 % of the kernel's instructions.  Now
+    // the list is read 192 entries ahead, the value words whose bit is set are appended to a ring in LDS (order kept), and a
+    // batch is the next 64 SURVIVORS: full lanes in the parking, 2.7x fewer batches, the same evaluations in the same order.
+    uint32_t qhead = 0, qn = 0;  // ring state (wave-uniform)
+    uint32_t pos = start;        // next list entry of the id stream
+    uint32_t g0 = 0, g1 = 0, g2 = 0; // value words of list entries pos + {0, 64, 128} + lane, loaded one batch ahead
+    // All loads are UNCONDITIONAL: an exec-masked load leaves the compiler merging old and new registers right behind the load,
+    // i.e. waiting for it at once, and the prefetch would be a prefetch in name only (it was, until round 2).  The id words come
+    // through a buffer descriptor of THIS tile's list: a read past its end returns 0 (no mask bit set) by the hardware's bounds
+    // check, and the address is lane * 4 + a scalar offset + an immediate: no vector instruction per load.
+    const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(values + start), 0, (int)((end - start) * 4u), 0x00020000);
+    const uint32_t lane4 = lane * 4u;
+    auto load_ids = [&]() {
+        const uint32_t so = (pos - start) * 4u;
+        g0 = __builtin_amdgcn_raw_buffer_load_b32(list_rsrc, lane4, so, 0);
+        g1 = __builtin_amdgcn_raw_buffer_load_b32(list_rsrc, lane4 + 256u, so, 0);
+        g2 = __builtin_amdgcn_raw_buffer_load_b32(list_rsrc, lane4 + 512u, so, 0);
     };
-    auto fetch = [&](uint32_t bb, uint32_t v) {
-        bool want = bb + lane < end;
-        if (MASKED) want = want && ((v >> mybit) & 1u);
+    const uint32_t mybitmask = 1u << mybit;
+    auto push = [&](uint32_t v, uint32_t first) {
+        bool want;
+        if (MASKED) want = (v & mybitmask) != 0u;  // (0 past the end of the list)
+        else want = first + lane < end;            // a plain id: 0 is one
+        const unsigned long long m = __ballot(want);
+        if (want) sQ[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qhead + qn)) & 255u] = v;
+        qn += (uint32_t)__popcll(m);
+    };
+    auto fill = [&]() { // until a batch is queued or the list is exhausted (one trip, except where the bit is rare: then the loads of the later trips are exposed)
+        while (qn < 64u && pos < end) {
+            push(g0, pos); push(g1, pos + 64u); push(g2, pos + 128u);
+            const uint32_t adv = end - pos < 192u ? end - pos : 192u;
+            staged += adv;
+            pos += adv;
+            if (pos < end) load_ids();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto take = [&](uint32_t& v) -> uint32_t { // the next batch: its value word for lane < the returned count
+        const uint32_t cnt = qn < 64u ? qn : 64u;
+        v = sQ[(qhead + lane) & 255u];
+        qhead = (qhead + cnt) & 255u;
+        qn -= cnt;
+        return cnt;
+    };
+    auto fetch = [&](uint32_t v, uint32_t cnt) {
         uint32_t g = MASKED ? (v & GS_ID_MASK) : v;
 #ifdef GS_PROFILING
         if (dbg & 2u) g &= 1023u; // gather from a cache-resident window
 #endif
-        g = want ? g : 0u;
+        g = lane < cnt ? g : 0u;
         const uint32_t* rec = reinterpret_cast<const uint32_t*>(gdata + (uint64_t)g * 4);
         r0 = *reinterpret_cast<const gs_u32x2*>(rec);
         r1 = *reinterpret_cast<const gs_u32x3*>(rec + 4);
         r2 = *reinterpret_cast<const gs_u32x4*>(rec + 8);
     };
+    uint32_t cnt = 0, vnext = 0;
     if (start < end) {
-        fetch_id(start);
-        vcur = gnext;
-        fetch(start, vcur);
-        fetch_id(start + 64);
+        load_ids();
+        fill();
+        cnt = take(vnext);
+        fetch(vnext, cnt);
     }
-    for (uint32_t bb = start; bb < end; bb += 64) {
-        const uint32_t cnt = (end - bb < 64u) ? end - bb : 64u;
-        staged += cnt;
+    while (cnt) {
         bool rel = false, npd = false;
         // The records fetched one batch ago are first needed HERE.  The empty asm pins that: without it the compiler copies the
         // loaded registers into the operand tuples of the LDS stores / packed multiplies right behind the loads, and the
@@ -379,7 +427,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
         const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
         const float op = __uint_as_float(r2.w);
-        if (lane < cnt && (!MASKED || ((vcur >> mybit) & 1u))) {
+        if (lane < cnt) {
             const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
             const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
             if (QCULL) {
@@ -427,12 +475,12 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 }
             }
         }
-        const uint32_t nb = bb + 64;
-        if (nb < end) {
-            vcur = gnext;
-            fetch(nb, vcur);
-            fetch_id(nb + 64);
-        }
+        // Order of issue: the id loads of the batch after the next one (inside fill), THEN the next batch's gathers.  The compiler
+        // waits for everything outstanding at the top of the loop (the ring's trip count is not known to it): with the ids issued
+        // last they were waited for a few instructions after their issue
+        fill();
+        const uint32_t cnt_next = take(vnext);
+        if (cnt_next) fetch(vnext, cnt_next);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t nrel = (uint32_t)__popcll(m);
@@ -445,8 +493,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         const float xlf = (float)(lane & 7u);
         auto walk = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
-            auto one = [&](uint32_t e) {
-                const float4 p0 = sP0[e];
+            auto one = [&](uint32_t e, const float4 p0, const float2 tt) { // p0 / tt: the entry's sP0 word / (fused) its row-table pair
                 if (EXACT) {
                     const float dx = p0.x - pxf;
                     const float4 p1 = sP1[e];
@@ -462,7 +509,6 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     cb += cond * p2v.z * alpha * T;
                     T = cond * test + (1.0f - cond) * T;
                 } else {
-                    const float2 tt = sT[trow + e];            // this pixel row's (B_r, A_r)
                     const float pw = __builtin_fmaf(xlf, __builtin_fmaf(xlf, p0.x, tt.x), tt.y); // log2(alpha / 0.99) before the clamp
                     float ea; // min(1, alpha / 0.99): v_exp_f32 with the clamp modifier (one instruction; a v_min on alpha was a second)
                     asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(ea) : "v"(pw));
@@ -510,9 +556,29 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     }
                 }
             };
+            // A group's LDS reads are ALL issued before its first evaluation, and a scheduling barrier keeps them there: left to
+            // itself the machine scheduler sometimes interleaves them with the arithmetic (read, wait, evaluate, read, wait ...),
+            // which costs 6 % of the kernel (config B 521 vs 488 us) -- and which of the two it picked changed with edits as far
+            // away as the kernel's first line (profiles/r03_notes.md)
+            auto group = [&](uint32_t e, auto n_tag) {
+                constexpr int G = decltype(n_tag)::value;
+                float4 p[G];
+                float2 t[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    p[k] = sP0[e + k];
+                    t[k] = EXACT ? make_float2(0.0f, 0.0f) : sT[trow + e + k]; // this pixel row's (B_r, A_r)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < G; ++k) one(e + k, p[k], t[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
             uint32_t e = 0;
-            for (; e + 4u <= nrel; e += 4u) { one(e); one(e + 1u); one(e + 2u); one(e + 3u); }
-            for (; e < nrel; ++e) one(e);
+            if (!EXACT) // eight per group: measured (config B) 4: 524 us, 6: 500, 8: 492, 12: 517 (the reads of a group share one wait)
+                for (; e + 8u <= nrel; e += 8u) group(e, std::integral_constant<int, 8>{});
+            for (; e + 4u <= nrel; e += 4u) group(e, std::integral_constant<int, 4>{});
+            for (; e < nrel; ++e) group(e, std::integral_constant<int, 1>{});
         };
         if (EXACT || __ballot(npd) != 0ull) walk(std::true_type{});
         else walk(std::false_type{});
@@ -521,6 +587,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (__ballot(!done) == 0ull) break; // this block's 64 pixels are final (exact criterion)
+        cnt = cnt_next;
     }
     // statistics: a tile's "staged before early exit" depth is the deepest any of its quadrants went
     // (tile_depth[] is zeroed with the control block; the host sums it)

@@ -17,7 +17,7 @@ for src in B.SOURCES:
     text = open(path).read() + "".join(open(os.path.join(B.HERE, h)).read() for h in ("gs_device.h", "gs_tight.h", "gs_kernels.h"))
     if any(m in text for m in macros):
         obj = os.path.join(odir, src.replace(".hip", ".o"))
-        subprocess.check_call([B.HIPCC] + B.FLAGS + flags + ["-c", path, "-o", obj])
+        subprocess.check_call([B.HIPCC] + B.FLAGS + B.FILE_FLAGS.get(src, []) + flags + ["-c", path, "-o", obj])
     else:
         obj = os.path.join(B.OUT, "obj", src.replace(".hip", ".o"))
     objs.append(obj)
