@@ -273,13 +273,24 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
 #pragma unroll 1
         for (int h = 0; h < 2 * NB / GRP; ++h) {
             float X[GRP], Y[GRP], Z[GRP], S[GRP];
+            // every position load of the group is issued before the first test: the loads are UNCONDITIONAL (index clamped; a
+            // conditional load is waited for right behind its issue) and a scheduling barrier keeps the tests behind them --
+            // the compiler had made four load / wait / test rounds of this
 #pragma unroll
             for (int k = 0; k < GRP; ++k) {
                 const uint32_t i = base + (uint32_t)(h * GRP + k) * 256u + tid;
-                const bool in = i < f.n;
-                X[k] = in ? s.px[i] : 0.0f; Y[k] = in ? s.py[i] : 0.0f; Z[k] = in ? s.pz[i] : 0.0f;
-                S[k] = (in && !f.full) ? s.smax[i] : 0.0f;
+                const uint32_t ic = i < f.n ? i : f.n - 1u;
+                X[k] = s.px[ic]; Y[k] = s.py[ic]; Z[k] = s.pz[ic];
+                S[k] = 0.0f;
             }
+            if (!f.full) { // (one branch around the group's four loads, not one per load with its wait behind it)
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    const uint32_t i = base + (uint32_t)(h * GRP + k) * 256u + tid;
+                    S[k] = s.smax[i < f.n ? i : f.n - 1u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < GRP; ++k) {
                 const uint32_t off = (uint32_t)(h * GRP + k) * 256u + tid;
