@@ -94,7 +94,9 @@ typedef struct gs_stats {
     uint64_t num_gaussians;       /* N                                                        */
     uint64_t num_visible;         /* gaussians that passed the cull (tile count > 0)          */
     uint64_t num_intersections;   /* I: what ExclusiveScanner.scan returns (renderer.ts:419)  */
-    uint64_t num_processed;       /* list entries staged by the blend before tile early-exit  */
+    uint64_t num_processed;       /* list entries the blend read before tile early-exit (per tile: the deepest of its walkers; the
+                                     id words are read 192 entries ahead of the records, so this runs up to 191 ahead of the last
+                                     entry whose record was fetched) */
     uint32_t num_tiles;           /* T over the whole canvas                                  */
     uint32_t sort_passes;         /* 8-bit radix passes executed                              */
     uint64_t frames;              /* frames rendered by this ctx                              */
@@ -203,11 +205,13 @@ int32_t gs_read_buffer(gs_ctx* ctx, int32_t which, void* dst, uint64_t size, uin
 int32_t gs_device_ptr(gs_ctx* ctx, int32_t which, void** d_ptr);
 int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 /* Tuning / profiling knobs. */
-#define GS_OPT_BLEND_ABLATION 1  /* bits 0-2 PROFILING ONLY, break the image (1 skip the pixel loop, 2 gather from a cache-resident window,
-                                    4 skip cull+loop); bits 3/4 pick another blend kernel with identical results (8 = one workgroup
-                                    per tile, tiles 16 and 32; 16 = one wave per whole 16-tile; default = one wave per 8x8 block);
-                                    bits 6/7 PROFILING ONLY (image intact): cap the quadrant kernel at 2 / 4 waves per SIMD;
-                                    bits 8-15: tile-column strip width of the quadrant kernel's XCD mapping (0 = automatic)     */
+#define GS_OPT_BLEND_ABLATION 1  /* bit 3 (8): the workgroup-per-tile blend kernel at tiles 16 and 32 (identical results; default = one
+                                    wave per 8x8 pixel block); bits 8-15: tile-column strip width of the default kernel's XCD mapping
+                                    (0 = automatic).  The remaining bits act only in the PROFILING build (csrc/build.py --profiling,
+                                    libgsplat_hip_prof.so; the product library ignores them): bits 0/1 break the image (1 skip the
+                                    pixel loop, 2 gather from a cache-resident window), bit 5 counts the evaluations' footprint
+                                    (tools/blend_footprint.py), bits 6/7 cap the kernel at 2 / 4 waves per SIMD, bit 16 records a
+                                    start / end stamp per walker (GS_BUF 11, tools/blend_profile.py)                              */
 #define GS_OPT_PERSISTENT_GRID 2 /* workgroups of the ticket-loop kernels (default 4 per CU)                          */
 #define GS_OPT_RESET_TIMING 3    /* start a new averaging window for gs_stats.stage_us_mean                           */
 #define GS_OPT_EMIT_ORDER 4      /* 1: the reference's gaussian-index emission order + sort by the full key (3-4 radix digits);
