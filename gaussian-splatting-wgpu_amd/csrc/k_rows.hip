@@ -111,14 +111,15 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
         }
         __syncthreads();
         uint32_t carry;
-        {   // owner of the wave's first slot: the last gaussian whose first slot is <= it
+        {   // owner of the wave's first slot: the last gaussian whose first slot is <= it.  goff is increasing: 64 samples 49 apart
+            // find the segment, its 49 entries the owner -- two LDS round trips instead of the twelve of a binary search
             const uint32_t x0 = s0 + w * (64 * RA_ITEMS);
-            uint32_t e = 0;
-#pragma unroll
-            for (int step = 2048; step >= 1; step >>= 1) {
-                const uint32_t m = e + step;
-                if (m < K && sh.u.g.goff[m] <= x0) e = m;
-            }
+            const uint32_t m1 = lane * 49u;
+            const uint32_t c1 = (uint32_t)__popcll(__ballot(m1 < K && sh.u.g.goff[m1 < K ? m1 : 0u] <= x0)); // >= 1: goff[0] <= s0 <= x0
+            const uint32_t b1 = (c1 ? c1 - 1u : 0u) * 49u;
+            const uint32_t m2 = b1 + lane;
+            const uint32_t c2 = (uint32_t)__popcll(__ballot(lane < 49u && m2 < K && sh.u.g.goff[m2 < K ? m2 : 0u] <= x0));
+            const uint32_t e = b1 + (c2 ? c2 - 1u : 0u);
             carry = e + 1u;
         }
         uint32_t ix[RA_ITEMS], iy[RA_ITEMS], iz[RA_ITEMS];
@@ -264,14 +265,17 @@ __device__ __forceinline__ void row_tables(RowTables& T, const GsControl* ctl, u
     if (tid == 255u) { T.ibase[256] = bc + ic; T.cbase[256] = bh + ih; }
     __syncthreads();
 }
-// tile row of chunk c (c < cbase[256]): the LAST r with cbase[r] <= c (rows without chunks share their successor's base)
+// tile row of chunk c (c < cbase[256]): the LAST r with cbase[r] <= c (rows without chunks share their successor's base).
+// cbase is non-decreasing, so r = the number of m in 1..255 with cbase[m] <= c: every wave counts them with four reads per lane
+// and four ballots -- one LDS round trip instead of the eight dependent ones of a binary search.
 __device__ __forceinline__ uint32_t row_of_chunk(const RowTables& T, uint32_t c) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = T.cbase[lane + 64u * k];
     uint32_t r = 0;
 #pragma unroll
-    for (int step = 128; step >= 1; step >>= 1) {
-        const uint32_t m = r + step;
-        if (m < 256u && T.cbase[m] <= c) r = m;
-    }
+    for (int k = 0; k < 4; ++k) r += (uint32_t)__popcll(__ballot(v[k] <= c && (lane + 64u * k) != 0u));
     return r;
 }
 
@@ -538,13 +542,17 @@ __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __r
             // ---- expansion: thread slot (w, j, lane) = instance s0 + w * RB_WSL + j * 64 + lane ----
             // owner of the wave's first slot: the last item whose prefix is <= it
             uint32_t carry;
-            {
+            {   // (P is non-decreasing and P[0] = 0: the owner is the number of m in 1..ni-1 with P[m] <= x0 -- eight reads per lane
+                // and eight ballots instead of nine dependent reads)
                 const uint32_t x0 = s0 + w * RB_WSL;
+                uint32_t pv[RB_CH / 64u];
+#pragma unroll
+                for (int k = 0; k < (int)(RB_CH / 64u); ++k) pv[k] = S.x.e.P[lane + 64u * k];
                 uint32_t e = 0;
 #pragma unroll
-                for (int step = (int)(RB_CH / 2u); step >= 1; step >>= 1) {
-                    const uint32_t m = e + step;
-                    if (m < ni && S.x.e.P[m] <= x0) e = m;
+                for (int k = 0; k < (int)(RB_CH / 64u); ++k) {
+                    const uint32_t m = lane + 64u * k;
+                    e += (uint32_t)__popcll(__ballot(m != 0u && m < ni && pv[k] <= x0));
                 }
                 carry = e + 1u;
             }
