@@ -246,6 +246,8 @@ template <bool TIGHT, int NB>
 __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
                                                              uint32_t* __restrict__ tile_counts, GsTightOut to) {
     __shared__ uint32_t s_ids[PRE_G * NB];
+    constexpr bool KEEP_POS = NB > 1;
+    __shared__ float s_pos[3][KEEP_POS ? PRE_G * NB : 1];
     __shared__ uint32_t s_cnt[2][4];
     __shared__ uint32_t s_misc[8];
     // TIGHT: per-survivor records of the row-item loop (written and read by the survivor's own wave)
@@ -305,7 +307,11 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
                     uint32_t at = 0;
                     if (lane == (uint32_t)__builtin_ctzll(b)) at = atomicAdd(&s_misc[1], (uint32_t)__popcll(b));
                     at = (uint32_t)__builtin_amdgcn_readlane((int)at, __builtin_ctzll(b));
-                    if (v) s_ids[at + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = off;
+                    if (v) {
+                        const uint32_t slot = at + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                        s_ids[slot] = off;
+                        if (KEEP_POS) { s_pos[0][slot] = X[k]; s_pos[1][slot] = Y[k]; s_pos[2][slot] = Z[k]; } // the survivor's position rides along
+                    }
                 }
             }
         }
@@ -353,7 +359,9 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         const bool active = v < nvis;
         const uint32_t i = base + s_ids[active ? v : nvis - 1u];
         const float4* geo = s.geo + (uint64_t)i * 2;
-        const float x = s.px[i], y = s.py[i], z = s.pz[i];
+        // (NB > 1: the position the cull loaded rides through LDS: three gathers per survivor less in a kernel bound by its memory pipeline)
+        const float x = KEEP_POS ? s_pos[0][v < nvis ? v : nvis - 1u] : s.px[i], y = KEEP_POS ? s_pos[1][v < nvis ? v : nvis - 1u] : s.py[i],
+                    z = KEEP_POS ? s_pos[2][v < nvis ? v : nvis - 1u] : s.pz[i];
         float ph[4], pv[4];
         m4_mulv(u.proj, x, y, z, ph);
         const float pw = 1.0f / (ph[3] + 0.0000001f);
