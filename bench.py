@@ -89,7 +89,9 @@ def pmc_traffic(stage, workload):
     """HBM bytes per launch of the stage's main kernel.  NOT measured by this run: PMC counters need their own rocprofv3
     passes (gpurun refuses them beside tracing), so the figure is replayed from the committed passes of tools/pmc_run.sh
     on the same workload (PMC_FILE; the `source` key of the result says so).  MI355X_MICROARCH.md (HBM): bytes =
-    (FETCH_SIZE + WRITE_SIZE) * 1024, and on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads, so it is doubled."""
+    (FETCH_SIZE + WRITE_SIZE) * 1024, and on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced stream (16 bytes per lane),
+    so it is doubled for the streaming stages -- but NOT for the blend: its reads are gathers of 8 + 12 + 16 bytes of a 64-byte record,
+    and tools/microbench/fetch_calib.hip (known bytes: profiles/r03_fetch_calib.txt) shows FETCH_SIZE counts those at 1.003x."""
     path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None, None
@@ -99,8 +101,11 @@ def pmc_traffic(stage, workload):
     for k in STAGE_KERNELS[stage]:
         c = next((v for name, v in js["kernels"].items() if name.startswith(k)), None)  # template arguments follow the name
         if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, {"kernel": k, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
-                                                                       "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count for 16 B/lane reads)",
+            ff = 1.0 if stage == "blend" else 2.0
+            how = ("FETCH_SIZE + WRITE_SIZE (record gathers are counted at 1.003x known bytes: profiles/r03_fetch_calib.txt)" if stage == "blend"
+                   else "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count for 16 B/lane streams)")
+            return (ff * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, {"kernel": k, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+                                                                       "correction": how,
                                                                        "source": PMC_FILE + " (committed rocprofv3 --pmc passes of the same workload, not this run)"}
     return None, None
 
