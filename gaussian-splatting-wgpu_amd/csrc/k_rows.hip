@@ -29,18 +29,27 @@
 
 typedef uint32_t gs_item3 __attribute__((ext_vector_type(3), aligned(4)));
 
-#define RA_ITEMS 6
+#ifndef RA_ITEMS
+#define RA_ITEMS 8 // measured (config B): 6: 101-105 us, 8: 98, 10: 96 (two workgroups per CU), 12: 111
+#endif
+#ifndef RA_WAVES
 #define RA_WAVES 8
+#endif
 #define RA_THREADS (RA_WAVES * 64)
-#define RA_TILE (RA_THREADS * RA_ITEMS) // 3072 slots per tile (8 waves x 6 items per lane): 36 KB of LDS for the reorder, three workgroups (24 waves) per CU
+#define RA_TILE (RA_THREADS * RA_ITEMS) // 4096 slots per tile (8 waves x 8 items per lane): 48 KB of LDS for the reorder, three workgroups (24 waves) per CU
 #define RA_AGG (1u << 30)
 #define RA_PREFIX (2u << 30)
 #define RA_FLAGS (3u << 30)
 #define RA_VALUE (~RA_FLAGS)
 
+#ifndef RB_CH
 #define RB_CH 512u   // items per chunk
+#endif
 #define RB_IT (RB_CH / 256u)
-#define RB_SB 2048u  // instances per sub-batch of the expansion (256 threads x 8): 25 KB of LDS, six workgroups per CU
+#ifndef RB_SB
+#define RB_SB 2048u
+#endif
+// RB_SB: instances per sub-batch of the expansion (256 threads x 8): 25 KB of LDS, six workgroups per CU
 #define RB_PER (RB_SB / 256u)
 #define RB_WSL (RB_SB / 4u) // slots of one wave
 
