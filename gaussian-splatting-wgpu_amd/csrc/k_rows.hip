@@ -676,6 +676,12 @@ __global__ __launch_bounds__(256) void gs_rows_rebuild_keys_kernel(const uint32_
     }
 }
 
+#ifndef RB_CNT_WG
+#define RB_CNT_WG 8u // workgroups per CU of the count ...
+#endif
+#ifndef RB_EXP_WG
+#define RB_EXP_WG 6u // ... and of the expansion (residency)
+#endif
 // ---- host launchers --------------------------------------------------------------------------------
 uint32_t gs_rows_sort_tiles(uint64_t row_cap) { return (uint32_t)((row_cap + RA_TILE - 1) / RA_TILE); }
 uint32_t gs_rows_chunks(uint64_t row_cap) { return (uint32_t)(row_cap / RB_CH + 256u); }
@@ -688,9 +694,9 @@ void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chu
     hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
                        row_cap, f.nty);
     if (mark) mark(mark_arg, 3);
-    hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * 8u), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
+    hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * RB_CNT_WG), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
     hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap);
-    hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * 6u), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
+    hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * RB_EXP_WG), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
                        (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, sticky, rep);
 }
 void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,
