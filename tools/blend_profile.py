@@ -2,6 +2,7 @@
 """Per-walker timeline of the blend kernel (GS_OPT_BLEND_ABLATION bit 16): lifetimes, concurrency over time, work per walker."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("GSPLAT_LIB", os.path.join(ROOT, "gaussian-splatting-wgpu_amd", "lib", "libgsplat_hip_prof.so"))  # the stamps exist in the profiling build only
 sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-wgpu_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import gsplat

@@ -1,5 +1,8 @@
 #!/bin/bash
 # usage: tools/sweep.sh "<bench args>" v1 v2 ...   -> runs bench.py with --blend-ablation v for each v
+# (most ablation bits act only in the PROFILING build: python gaussian-splatting-wgpu_amd/csrc/build.py --profiling; used here when present)
+PROF=$(dirname "$0")/../gaussian-splatting-wgpu_amd/lib/libgsplat_hip_prof.so
+[ -f "$PROF" ] && export GSPLAT_LIB=$(cd "$(dirname "$PROF")" && pwd)/libgsplat_hip_prof.so
 ARGS=$1; shift
 mkdir -p gpurun_out
 for v in "$@"; do
