@@ -57,6 +57,49 @@ def test_frame_fused_mode(oracle, n, W, H, ts):
     r.destroy()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 191, 192, 193, 255, 256, 257, 449, 1300])
+def test_blend_id_stream_list_lengths(oracle, n):
+    """The blend reads a tile's list 192 entries ahead and queues the entries of its 8x8 block in a 256-entry ring (k_blend.hip):
+    lists whose lengths sit on every boundary of that machinery (one step of the stream, the lookahead, the ring, a ring that wraps
+    several times).  One tile and a half: n faint splats over the whole 16x16 tile (every block's bit set: dense survivors) plus
+    n / 3 small ones on single blocks of the neighbouring tile (sparse bits: the stream needs several steps per batch).  Low
+    opacities keep every pixel alive to the end of its list.  EXACT: bit-equal to the oracle; fused: within 1e-4."""
+    from gsplat import _abi
+    from gpu_checks import check_image
+    W, H, ts = 32, 16, 16
+    rng = np.random.Generator(np.random.Philox(key=[91, n]))
+    m = max(n // 3, 1)
+    s = np.zeros((n + m, 80), dtype=np.float32)
+    # big, faint: centre somewhere in tile 0, sigma ~ 10 pixels
+    px = np.concatenate([rng.uniform(2.0, 14.0, n), 16.0 + rng.uniform(1.0, 15.0, m)]).astype(np.float32)
+    py = np.concatenate([rng.uniform(2.0, 14.0, n), rng.uniform(1.0, 15.0, m)]).astype(np.float32)
+    s[:, 0] = 2.0 * px / W - 1.0
+    s[:, 1] = 2.0 * py / H - 1.0
+    s[:, 2] = 1.0 + rng.uniform(0.0, 3.0, n + m).astype(np.float32)  # depth buckets spread: the list order is exercised too
+    s[:n, 4:7] = np.log(rng.uniform(0.4, 0.9, (n, 3))).astype(np.float32)
+    s[n:, 4:7] = np.log(rng.uniform(0.02, 0.05, (m, 3))).astype(np.float32)
+    s[:, 8] = 1.0
+    s[:, 8:12] += 0.2 * rng.standard_normal((n + m, 4)).astype(np.float32)
+    s[:n, 12] = rng.uniform(-5.0, -3.5, n).astype(np.float32)   # opacity 0.007 .. 0.03: above 1/255, far from saturating a pixel
+    s[n:, 12] = rng.uniform(-3.0, -1.0, m).astype(np.float32)
+    s[:, 16:19] = rng.uniform(0.2, 1.5, (n + m, 3)).astype(np.float32)
+    u = np.zeros(40, dtype=np.float32)
+    u[0] = u[5] = u[10] = u[15] = 1.0
+    u[16] = u[21] = u[26] = u[31] = 1.0
+    u[35] = u[36] = 0.5
+    u[37], u[38] = 16.0, 8.0   # focal: W / 2, H / 2 pixels per unit at depth 1
+    u[39] = 1.0
+    ref = oracle.render(s, u, W, H, ts, want_illcond=True)
+    assert ref["ranges"][0] >= min(n, 1)  # tile 0 really holds the long list
+    for flags, exact in ((_abi.GS_FLAG_EXACT_BLEND, True), (0, False)):
+        r = _mk(s, W, H, ts, flags=flags)
+        r.render_uniforms(u)
+        r.wait()
+        check_product_lists(r, ref, oracle, W, H, ts)
+        check_image(r, ref, exact, max_ill=0.5)
+        r.destroy()
+
+
 def test_fused_blend_splat_centres_on_pixel_centres(oracle):
     """The fused blend's loop drops the reference's `power <= 0` test (compute_tiles.wgsl:61) for batches whose conics are all
     positive definite: there the power can only exceed 0 by rounding, which happens where dx, dy are (almost) 0.  This scene puts
