@@ -255,23 +255,52 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
 // Chunk geometry shared by the count / scan / expand kernels: tile row r holds items [ibase[r], ibase[r] + cnt[r]) of the
 // row-sorted array and chunks [cbase[r], cbase[r + 1]) of RB_CH items each (the last one shorter).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long long v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)v, d, 64), hi = __shfl_up((uint32_t)(v >> 32), d, 64);
+        if ((int)lane >= d) v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
 struct RowTables {
-    uint32_t ibase[257]; // exclusive scan of GsControl::rowhist
-    uint32_t cbase[257]; // exclusive scan of ceil(rowhist / RB_CH)
+    uint32_t ibase[257]; // exclusive scan of GsControl::rowhist, clamped to the arrays' capacity
+    uint32_t cbase[257]; // exclusive scan of ceil(items / RB_CH)
     uint32_t w4[8];
 };
-// 256 threads; leaves the tables valid after its last barrier
-__device__ __forceinline__ void row_tables(RowTables& T, const GsControl* ctl, uint32_t tid) {
+// The first 256 threads of the workgroup build the tables (every thread calls: the others only take the barriers); valid after
+// the last barrier.  row_cap: slots the row-item arrays hold.  A frame whose items do not fit (the arena overflowed: it is
+// flagged and rendered again with grown arrays) still counted ALL its items in the histogram while the projection dropped the
+// ones that did not fit: the rows' extents are clamped to the arrays here, so that nothing is read past them (found by
+// tests/test_gpu_parity.py::test_row_item_arena_overflow_regrows_and_rerenders: a memory fault).
+__device__ __forceinline__ void row_tables(RowTables& T, const GsControl* ctl, uint32_t row_cap, uint32_t tid) {
     const uint32_t lane = tid & 63, w = tid >> 6;
-    const uint32_t c = gs_rowhist(ctl, tid), ch = (c + RB_CH - 1u) / RB_CH;
-    const uint32_t ic = wave_incl_scan(c, lane), ih = wave_incl_scan(ch, lane);
-    if (lane == 63) { T.w4[w] = ic; T.w4[4 + w] = ih; }
+    const bool on = tid < 256u;
+    const uint32_t c = on ? gs_rowhist(ctl, tid) : 0u;
+    const unsigned long long ic = wave_incl_scan64(c, lane); // (64 bits: the sum of the histogram can pass 2^32 before the clamp)
+    if (on && lane == 63) { T.w4[w] = (uint32_t)(ic > 0xFFFFFFFFull ? 0xFFFFFFFFull : ic); }
     __syncthreads();
-    uint32_t bc = 0, bh = 0;
-    for (uint32_t k = 0; k < w; ++k) { bc += T.w4[k]; bh += T.w4[4 + k]; }
-    T.ibase[tid] = bc + ic - c;
-    T.cbase[tid] = bh + ih - ch;
-    if (tid == 255u) { T.ibase[256] = bc + ic; T.cbase[256] = bh + ih; }
+    uint32_t i0 = 0, cc = 0;
+    if (on) {
+        unsigned long long b = ic - c;
+        for (uint32_t k = 0; k < w; ++k) b += T.w4[k];
+        const unsigned long long e = b + c;
+        i0 = b > row_cap ? row_cap : (uint32_t)b;
+        const uint32_t i1 = e > row_cap ? row_cap : (uint32_t)e;
+        cc = i1 - i0;
+        T.ibase[tid] = i0;
+        if (tid == 255u) T.ibase[256] = i1;
+    }
+    const uint32_t ch = (cc + RB_CH - 1u) / RB_CH;
+    const uint32_t ih = wave_incl_scan(ch, lane);
+    if (on && lane == 63) T.w4[4 + w] = ih;
+    __syncthreads();
+    if (on) {
+        uint32_t bh = 0;
+        for (uint32_t k = 0; k < w; ++k) bh += T.w4[4 + k];
+        T.cbase[tid] = bh + ih - ch;
+        if (tid == 255u) T.cbase[256] = bh + ih;
+    }
     __syncthreads();
 }
 // tile row of chunk c (c < cbase[256]): the LAST r with cbase[r] <= c (rows without chunks share their successor's base).
@@ -289,12 +318,12 @@ __device__ __forceinline__ uint32_t row_of_chunk(const RowTables& T, uint32_t c)
 }
 
 __global__ __launch_bounds__(256) void gs_rows_count_kernel(const uint32_t* __restrict__ rows, const GsControl* ctl, uint32_t* __restrict__ M3,
-                                                            uint32_t chunk_cap) {
+                                                            uint32_t chunk_cap, uint32_t row_cap) {
     __shared__ RowTables T;
     __shared__ int s_diff[257];
     __shared__ uint32_t s_w[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    row_tables(T, ctl, tid);
+    row_tables(T, ctl, row_cap, tid);
     uint32_t nch = T.cbase[256];
     if (nch > chunk_cap) nch = chunk_cap;
     for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
@@ -330,28 +359,13 @@ __global__ __launch_bounds__(256) void gs_rows_count_kernel(const uint32_t* __re
 // One workgroup of 1024 threads per tile row: thread (column c, part p) takes a quarter of the row's chunks.
 // tileoff[r * 256 + c] = instances of row r in columns < c; rowtot[r] = instances of the row (both saturate at 2^32 - 1).
 __global__ __launch_bounds__(1024) void gs_rows_scan_kernel(const GsControl* ctl, uint32_t* __restrict__ M3, uint32_t* __restrict__ tileoff,
-                                                            uint32_t* __restrict__ rowtot, uint32_t chunk_cap) {
+                                                            uint32_t* __restrict__ rowtot, uint32_t chunk_cap, uint32_t row_cap) {
     __shared__ RowTables T;
     __shared__ unsigned long long s_part[4][256];
     __shared__ unsigned long long s_ex[256];
     __shared__ unsigned long long s_w[4];
     const uint32_t tid = threadIdx.x, c = tid & 255u, p = tid >> 8, r = blockIdx.x;
-    {
-        const uint32_t lane = tid & 63, w = tid >> 6;
-        uint32_t cc = 0, ch = 0;
-        if (tid < 256u) { cc = gs_rowhist(ctl, tid); ch = (cc + RB_CH - 1u) / RB_CH; }
-        const uint32_t ic = wave_incl_scan(cc, lane), ih = wave_incl_scan(ch, lane);
-        if (tid < 256u && lane == 63) { T.w4[w] = ic; T.w4[4 + w] = ih; }
-        __syncthreads();
-        if (tid < 256u) {
-            uint32_t bc = 0, bh = 0;
-            for (uint32_t k = 0; k < w; ++k) { bc += T.w4[k]; bh += T.w4[4 + k]; }
-            T.ibase[tid] = bc + ic - cc;
-            T.cbase[tid] = bh + ih - ch;
-            if (tid == 255u) { T.ibase[256] = bc + ic; T.cbase[256] = bh + ih; }
-        }
-        __syncthreads();
-    }
+    row_tables(T, ctl, row_cap, tid);
     uint32_t c0 = T.cbase[r], c1 = T.cbase[r + 1];
     if (c0 > chunk_cap) c0 = chunk_cap;
     if (c1 > chunk_cap) c1 = chunk_cap;
@@ -426,14 +440,14 @@ struct ExpandShared {
 __global__ __launch_bounds__(256) void gs_rows_expand_kernel(const uint32_t* __restrict__ rows, GsControl* ctl, const uint32_t* __restrict__ M3,
                                                              const uint32_t* __restrict__ tileoff, const uint32_t* __restrict__ rowtot, GsFrame f,
                                                              uint32_t* __restrict__ values, uint32_t* __restrict__ ranges, uint32_t chunk_cap,
-                                                             uint32_t* sticky, GsReport* rep) {
+                                                             uint32_t row_cap, uint32_t* sticky, GsReport* rep) {
     __shared__ ExpandShared S;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t ns = f.tile_size >= 16u ? 2u : 1u;
     const uint32_t hole = f.ntx < 128u ? 127u : 255u; // the digit of the slots past a sub-batch's end: no tile column has it
     const int nbits = f.ntx < 128u ? 7 : 8;
-    row_tables(S.T, ctl, tid);
+    row_tables(S.T, ctl, row_cap, tid);
     {   // first instance of every tile row
         const uint32_t v = tid < f.nty ? rowtot[tid] : 0u;
         unsigned long long incl = v;
@@ -694,10 +708,10 @@ void gs_launch_rows(const uint32_t* arena, const void* grec, const uint32_t* chu
     hipLaunchKernelGGL(gs_rows_sort_kernel, dim3(cus * 3u), dim3(RA_THREADS), 0, st, arena, (const uint4*)grec, chunk_table, rows_sorted, ctl, sort_status,
                        row_cap, f.nty);
     if (mark) mark(mark_arg, 3);
-    hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * RB_CNT_WG), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap);
-    hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap);
+    hipLaunchKernelGGL(gs_rows_count_kernel, dim3(cus * RB_CNT_WG), dim3(256), 0, st, (const uint32_t*)rows_sorted, (const GsControl*)ctl, M3, chunk_cap, row_cap);
+    hipLaunchKernelGGL(gs_rows_scan_kernel, dim3(f.nty), dim3(1024), 0, st, (const GsControl*)ctl, M3, tileoff, rowtot, chunk_cap, row_cap);
     hipLaunchKernelGGL(gs_rows_expand_kernel, dim3(cus * RB_EXP_WG), dim3(256), 0, st, (const uint32_t*)rows_sorted, ctl, (const uint32_t*)M3,
-                       (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, sticky, rep);
+                       (const uint32_t*)tileoff, (const uint32_t*)rowtot, f, values, ranges, chunk_cap, row_cap, sticky, rep);
 }
 void gs_launch_rows_rebuild_keys(const uint32_t* ranges, uint32_t T, const uint32_t* vals, const uint32_t* counts, uint32_t count, uint32_t n,
                                  uint32_t* keys, hipStream_t st) {

@@ -100,6 +100,52 @@ def test_blend_id_stream_list_lengths(oracle, n):
         r.destroy()
 
 
+def test_row_item_arena_overflow_regrows_and_rerenders(oracle):
+    """The tight projection hands out row-item slots from an arena of max(2 N, 1 Mi) slots (16 sharded bump cursors); a frame that
+    needs more is flagged, gs_wait grows the arena (and here the value capacity too) and renders the frame again.  100 000 large, faint
+    splats on a 512x512 canvas of 8-pixel tiles take about fourteen tile rows each: 1.1+ M slots, 15+ M instances."""
+    from gsplat import _abi
+    from gpu_checks import check_image
+    W = H = 512
+    ts = 8
+    n = 100000
+    rng = np.random.Generator(np.random.Philox(key=[123, 7]))
+    s = np.zeros((n, 80), dtype=np.float32)
+    s[:, 0:2] = rng.uniform(-0.95, 0.95, (n, 2)).astype(np.float32)
+    s[:, 2] = 1.0 + rng.uniform(0.0, 4.0, n).astype(np.float32)
+    s[:, 4:7] = np.log(rng.uniform(0.07, 0.12, (n, 3)) * s[:, 2:3]).astype(np.float32)  # ~18-30 pixels of sigma at every depth
+    s[:, 8] = 1.0
+    s[:, 8:12] += 0.3 * rng.standard_normal((n, 4)).astype(np.float32)
+    s[:, 12] = rng.uniform(-3.5, -2.5, n).astype(np.float32)  # opacity 0.03 .. 0.08
+    s[:, 16:19] = rng.uniform(0.2, 1.5, (n, 3)).astype(np.float32)
+    u = np.zeros(40, dtype=np.float32)
+    u[0] = u[5] = u[10] = 1.0
+    u[15] = 1.0
+    # proj: x, y pass through, w = z (a plain perspective divide), so that splats keep their screen size over the depth range
+    u[16] = u[21] = 1.0
+    u[26] = 1.0
+    u[27] = 1.0  # row 3 (w) takes z: column-major m[2*4+3]
+    u[35] = u[36] = 1.0
+    u[37] = u[38] = 256.0
+    u[39] = 1.0
+    ref = oracle.render(s, u, W, H, ts, want_illcond=True)
+    r = _mk(s, W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    cap0 = r.stats()["row_capacity"]
+    r.render_uniforms(u)
+    r.wait()
+    st = r.stats()
+    assert st["tight_binning"] == 1
+    assert st["num_row_slots"] > cap0, "the scene is meant to outgrow the default arena (%d slots of %d)" % (st["num_row_slots"], cap0)
+    assert st["row_capacity"] >= st["num_row_slots"] and st["capacity"] >= st["num_intersections"]
+    check_product_lists(r, ref, oracle, W, H, ts)
+    check_image(r, ref, True)
+    r.render_uniforms(u)  # and again with the grown arrays: nothing is flagged any more
+    r.wait()
+    assert r.stats()["row_capacity"] == st["row_capacity"]
+    check_image(r, ref, True)
+    r.destroy()
+
+
 def test_fused_blend_splat_centres_on_pixel_centres(oracle):
     """The fused blend's loop drops the reference's `power <= 0` test (compute_tiles.wgsl:61) for batches whose conics are all
     positive definite: there the power can only exceed 0 by rounding, which happens where dx, dy are (almost) 0.  This scene puts
