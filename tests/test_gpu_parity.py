@@ -144,6 +144,18 @@ def test_row_item_arena_overflow_regrows_and_rerenders(oracle):
     assert r.stats()["row_capacity"] == st["row_capacity"]
     check_image(r, ref, True)
     r.destroy()
+    # the same overflow in an EARLIER frame of a batch (two frames enqueued, one wait): reported, arrays grown, last frame complete
+    r = _mk(s, W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)
+    r.render_uniforms(u)
+    r.render_uniforms(u)
+    with pytest.raises(_abi.GsError) as e:
+        r.wait()
+    assert e.value.code == -9
+    st2 = r.stats()
+    assert st2["row_capacity"] >= st2["num_row_slots"] > cap0 and st2["truncated_frames"] == 1
+    check_image(r, ref, True)
+    r.destroy()
 
 
 def test_fused_blend_splat_centres_on_pixel_centres(oracle):

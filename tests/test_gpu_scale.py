@@ -313,9 +313,11 @@ def test_tile_ids_wider_than_16_bits(oracle):
     r.destroy()
 
 
-def test_truncated_frames_are_reported(oracle):
+@pytest.mark.parametrize("tile_cull", [0, 1])
+def test_truncated_frames_are_reported(oracle, tile_cull):
     """Several frames per gs_wait: when an EARLIER frame overflows the capacity, gs_wait must say so (GS_ERR_TRUNCATED), grow
-    the capacity, and the next round must be clean."""
+    the capacity, and the next round must be clean.  tile_cull 0: the reference's binning (instance keys and sort); 1: the tight
+    row pipeline (the expansion is what meets the end of the value array)."""
     from conftest import scene
     from gsplat import _abi
     n, W, H = 30000, 320, 192
@@ -323,16 +325,17 @@ def test_truncated_frames_are_reported(oracle):
     us = [orbit_uniforms(W, H, step=k) for k in (3, 19, 40)]
     need = max(oracle.render(s, u, W, H, 16)["num_intersections"] for u in us)
     r = make_renderer(s, W, H, 16, max_intersections=4096, flags=_abi.GS_FLAG_EXACT_BLEND)
-    r.set_option(_abi.GS_OPT_TILE_CULL, 0)
+    r.set_option(_abi.GS_OPT_TILE_CULL, tile_cull)
     r.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 1)  # all three frames on the one context
-    assert need > 4096
+    assert need > 4 * 4096  # (the tight lists keep about half of the reference's instances: still far beyond the capacity)
     for u in us:
         r.render_uniforms(u)
     with pytest.raises(_abi.GsError) as e:
         r.wait()
     assert e.value.code == -9 and "truncated" in str(e.value)
     st = r.stats()
-    assert st["capacity"] >= need and st["truncated_frames"] == 2
+    assert st["tight_binning"] == tile_cull
+    assert st["capacity"] >= (st["num_intersections"] if tile_cull else need) and st["truncated_frames"] == 2
     ref = oracle.render(s, us[-1], W, H, 16)
     np.testing.assert_array_equal(r.read_rgba8(), ref["rgba8"])  # the last frame was re-rendered and is complete
     for u in us:
