@@ -158,6 +158,74 @@ def test_row_item_arena_overflow_regrows_and_rerenders(oracle):
     r.destroy()
 
 
+def test_row_items_of_very_long_runs(oracle):
+    """A row item stores the sub-block intervals of its run in 8 bits each (gs_tight.h); a run of more than 127 tiles has more
+    sub-block columns than that and is flagged whole (conservative).  A 2032x32 canvas of 8-pixel tiles (254 tile columns, the widest
+    the row pipeline takes) with splats stretched over most of its width, mixed with small ones; tile 16 on 4064x32 likewise."""
+    from gsplat import _abi
+    from gpu_checks import check_image
+    for W, H, ts in ((2032, 32, 8), (4064, 32, 16)):
+        n = 600
+        rng = np.random.Generator(np.random.Philox(key=[321, ts]))
+        s = np.zeros((n, 80), dtype=np.float32)
+        s[:, 0] = rng.uniform(-0.9, 0.9, n).astype(np.float32)
+        s[:, 1] = rng.uniform(-0.9, 0.9, n).astype(np.float32)
+        s[:, 2] = 1.0 + rng.uniform(0.0, 2.0, n).astype(np.float32)
+        long_ = rng.uniform(0.0, 1.0, n) < 0.3
+        sx = np.where(long_, rng.uniform(0.15, 0.6, n), rng.uniform(0.002, 0.01, n))   # in units of the half width: up to ~1200 pixels of sigma
+        sy = rng.uniform(0.05, 0.4, n)                                                 # 1 .. 6 pixels of sigma (half height = 16 pixels)
+        s[:, 4] = np.log(sx * s[:, 2]).astype(np.float32)
+        s[:, 5] = np.log(sy * s[:, 2]).astype(np.float32)
+        s[:, 6] = np.log(0.01).astype(np.float32)
+        s[:, 8] = 1.0
+        s[:, 11] = (0.02 * rng.standard_normal(n)).astype(np.float32)  # a slight roll: the runs are not axis-aligned
+        s[:, 12] = rng.uniform(-3.0, 1.0, n).astype(np.float32)
+        s[:, 16:19] = rng.uniform(0.2, 1.5, (n, 3)).astype(np.float32)
+        u = np.zeros(40, dtype=np.float32)
+        u[0] = u[5] = u[10] = u[15] = 1.0
+        u[16] = u[21] = 1.0
+        u[26] = 1.0
+        u[27] = 1.0
+        u[35] = u[36] = 1.0
+        u[37], u[38] = W / 2.0, H / 2.0
+        u[39] = 1.0
+        ref = oracle.render(s, u, W, H, ts, want_illcond=True)
+        rect = ref["gdata"].reshape(-1, 16)[:, 12:16].astype(np.int64)
+        vis = ref["tile_counts"] > 0
+        assert ((rect[vis, 2] - rect[vis, 0]) > 200).sum() >= 20  # rects wider than 200 tiles really occur
+        for flags, exact in ((_abi.GS_FLAG_EXACT_BLEND, True), (0, False)):
+            r = _mk(s, W, H, ts, flags=flags)
+            r.render_uniforms(u)
+            r.wait()
+            assert r.stats()["tight_binning"] == 1
+            check_product_lists(r, ref, oracle, W, H, ts)
+            check_image(r, ref, exact, max_ill=0.5)
+            r.destroy()
+
+
+@pytest.mark.parametrize("shape", [(4080, 32, 16), (32, 4080, 16), (2040, 2040, 8), (2048, 64, 8)])
+def test_row_pipeline_at_its_grid_limits(oracle, shape):
+    """Row items hold tile rows and columns in 8 bits: canvases of exactly 255 tile columns / rows (the widest and tallest the
+    row pipeline takes: digit 255 is the row sort's and the expansion's `hole`), 255 x 255 tiles, and 256 columns (one too many: the
+    product frame must fall back to the reference's binning by itself).  EXACT image bit-equal, lists checked where tight."""
+    from conftest import scene
+    from gsplat import _abi
+    from gpu_checks import check_image
+    W, H, ts = shape
+    s = scene(20000)
+    u = _uniforms(W, H, step=13)
+    ref = oracle.render(s, u, W, H, ts)
+    r = _mk(s, W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.render_uniforms(u)
+    r.wait()
+    ntx, nty = -(-W // ts), -(-H // ts)
+    assert r.stats()["tight_binning"] == (1 if max(ntx, nty) <= 255 else 0)
+    if r.stats()["tight_binning"]:
+        check_product_lists(r, ref, oracle, W, H, ts)
+    check_image(r, ref, True)
+    r.destroy()
+
+
 def test_fused_blend_splat_centres_on_pixel_centres(oracle):
     """The fused blend's loop drops the reference's `power <= 0` test (compute_tiles.wgsl:61) for batches whose conics are all
     positive definite: there the power can only exceed 0 by rounding, which happens where dx, dy are (almost) 0.  This scene puts
