@@ -246,7 +246,7 @@ template <bool TIGHT, int NB>
 __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s, GsUniforms u, GsFrame f, uint4* __restrict__ gdata,
                                                              uint32_t* __restrict__ tile_counts, GsTightOut to) {
     __shared__ uint32_t s_ids[PRE_G * NB];
-    constexpr bool KEEP_POS = NB > 1;
+    constexpr bool KEEP_POS = NB == 2; // (whole canvas; at NB = 8 the 48 KB would halve the slab workgroups per CU: 65-100 -> 128-184 us per rank)
     __shared__ float s_pos[3][KEEP_POS ? PRE_G * NB : 1];
     __shared__ uint32_t s_cnt[2][4];
     __shared__ uint32_t s_misc[8];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, PRE_WAVES) void gs_preprocess_kernel(GsScene s
         const bool active = v < nvis;
         const uint32_t i = base + s_ids[active ? v : nvis - 1u];
         const float4* geo = s.geo + (uint64_t)i * 2;
-        // (NB > 1: the position the cull loaded rides through LDS: three gathers per survivor less in a kernel bound by its memory pipeline)
+        // (NB = 2: the position the cull loaded rides through LDS: three gathers per survivor less in a kernel bound by its memory pipeline)
         const float x = KEEP_POS ? s_pos[0][v < nvis ? v : nvis - 1u] : s.px[i], y = KEEP_POS ? s_pos[1][v < nvis ? v : nvis - 1u] : s.py[i],
                     z = KEEP_POS ? s_pos[2][v < nvis ? v : nvis - 1u] : s.pz[i];
         float ph[4], pv[4];
