@@ -120,14 +120,20 @@ __global__ __launch_bounds__(RA_THREADS) void gs_rows_sort_kernel(const uint32_t
         }
         __syncthreads();
         uint32_t carry;
-        {   // owner of the wave's first slot: the last gaussian whose first slot is <= it.  goff is increasing: 64 samples 49 apart
-            // find the segment, its 49 entries the owner -- two LDS round trips instead of the twelve of a binary search
+        {   // owner of the wave's first slot: the last gaussian whose first slot is <= it.  goff is increasing: 64 samples RA_STR apart
+            // find the segment, its RA_STR entries the owner -- two LDS round trips instead of the twelve of a binary search
+            constexpr uint32_t RA_STR = (RA_TILE + 8u + 63u) / 64u; // 64 samples cover every k < K <= RA_TILE + 8
+            static_assert(RA_STR * 64u >= RA_TILE + 8u && RA_STR <= 128u, "the two-level owner search covers the tile's gaussians");
             const uint32_t x0 = s0 + w * (64 * RA_ITEMS);
-            const uint32_t m1 = lane * 49u;
+            const uint32_t m1 = lane * RA_STR;
             const uint32_t c1 = (uint32_t)__popcll(__ballot(m1 < K && sh.u.g.goff[m1 < K ? m1 : 0u] <= x0)); // >= 1: goff[0] <= s0 <= x0
-            const uint32_t b1 = (c1 ? c1 - 1u : 0u) * 49u;
-            const uint32_t m2 = b1 + lane;
-            const uint32_t c2 = (uint32_t)__popcll(__ballot(lane < 49u && m2 < K && sh.u.g.goff[m2 < K ? m2 : 0u] <= x0));
+            const uint32_t b1 = (c1 ? c1 - 1u : 0u) * RA_STR;
+            uint32_t c2 = 0;
+#pragma unroll
+            for (uint32_t t2 = 0; t2 < (RA_STR + 63u) / 64u; ++t2) {
+                const uint32_t o2 = t2 * 64u + lane, m2 = b1 + o2;
+                c2 += (uint32_t)__popcll(__ballot(o2 < RA_STR && m2 < K && sh.u.g.goff[m2 < K ? m2 : 0u] <= x0));
+            }
             const uint32_t e = b1 + (c2 ? c2 - 1u : 0u);
             carry = e + 1u;
         }

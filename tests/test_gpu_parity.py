@@ -226,6 +226,26 @@ def test_row_pipeline_at_its_grid_limits(oracle, shape):
     r.destroy()
 
 
+def test_row_sort_tiles_of_single_slot_gaussians(oracle):
+    """A row-sort tile (4096 slots) whose gaussians have ONE slot each holds 4096 gaussians -- the most its owner search has to
+    cover (k_rows.hip: 64 samples + one segment).  A 17-pixel wide canvas of 32-pixel tiles: one tile column, almost every visible
+    gaussian in one tile row.  Found by tools/fuzz_product.py when the search still assumed 3072-slot tiles: misordered lists."""
+    from gsplat import _abi, synth
+    from gpu_checks import check_image
+    W, H, ts = 17, 334, 32
+    s = synth.bicycle_like(60000, synth.BASE_SEED + 122)
+    u = synth.orbit_camera(5, W, H).uniforms(W, H)
+    ref = oracle.render(s, u, W, H, ts)
+    r = _mk(s, W, H, ts, flags=_abi.GS_FLAG_EXACT_BLEND)
+    r.render_uniforms(u)
+    r.wait()
+    st = r.stats()
+    assert st["tight_binning"] == 1 and st["num_row_slots"] < 1.2 * st["num_visible"] and st["num_visible"] > 30000
+    check_product_lists(r, ref, oracle, W, H, ts)
+    check_image(r, ref, True)
+    r.destroy()
+
+
 def test_fused_blend_splat_centres_on_pixel_centres(oracle):
     """The fused blend's loop drops the reference's `power <= 0` test (compute_tiles.wgsl:61) for batches whose conics are all
     positive definite: there the power can only exceed 0 by rounding, which happens where dx, dy are (almost) 0.  This scene puts
