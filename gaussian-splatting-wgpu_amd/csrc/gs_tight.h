@@ -62,7 +62,10 @@ __device__ __forceinline__ TightG tight_setup(float uvx, float uvy, float cx, fl
     g.qb = (g.lim2 * cx) * 1.00001f;
     const bool pd = (cx > 0.0f) && (cz > 0.0f) && (D > 0.0f);
     const bool fin = tight_finite(g.gx) && tight_finite(g.gy) && tight_finite(cx) && tight_finite(cy) && tight_finite(cz) && tight_finite(g.rcx);
-    if (lim < 0.0f) { g.mode = 0u; return g; }                                  // (-inf included; NaN falls through to mode 2)
+    // non-finite geometry first: the reference's arithmetic turns such a splat's contribution into 0 * NaN = NaN on every pixel of
+    // its rect's tiles whatever its opacity, so it keeps the whole rect (mode 2) even where its opacity alone would drop it
+    if (!fin) { g.mode = 2u; return g; }
+    if (lim < 0.0f) { g.mode = 0u; return g; }                                  // (-inf included; a NaN opacity falls through to mode 2)
     // Dlo: a lower bound of cx cz - cy^2 that also covers the inflation of tight_chord's discriminant (1e-5 of its terms), so
     // that xmax / ymax bound every chord tight_chord accepts: a row beyond ymax then yields nothing whether it is looked at or
     // skipped (tight_rows), and whole-canvas and slab frames agree instance for instance
