@@ -23,6 +23,8 @@ for k in range(seed0, seed0 + cases):
     W = int(rng.integers(17, 1400)); H = int(rng.integers(17, 900))
     if rng.random() < 0.15: W = ts * int(rng.integers(1, 60)); H = ts * int(rng.integers(1, 40))  # exact multiples of the tile
     n = int(rng.choice([1, 7, 64, 300, 3000, 20000, 60000, 250000]))
+    if os.environ.get("FUZZ_BIG"):  # a few large cases: canvases up to 4K, up to 3 M splats
+        n = int(rng.choice([500_000, 1_200_000, 3_000_000])); W = int(rng.integers(1200, 3841)); H = int(rng.integers(700, 2161))
     step = int(rng.integers(0, 64))
     mod = float(rng.choice([0.3, 1.0, 1.0, 1.0, 2.0, 4.0]))
     s = synth.bicycle_like(n, synth.BASE_SEED + 100 + k)
