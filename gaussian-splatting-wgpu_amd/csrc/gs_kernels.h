@@ -14,6 +14,7 @@ struct GsPreprocessLaunch { // the projection's launch as data (its uniforms are
 void gs_preprocess_prepare(GsPreprocessLaunch& L, const GsScene& s, const GsUniforms& u, const GsFrame& f, void* gdata, uint32_t* counts,
                            bool tight, uint32_t* arena, uint32_t* rowptr, GsControl* ctl, uint32_t tight_nb = 0);
 void gs_launch_preprocess(GsPreprocessLaunch& L, hipStream_t st);
+void gs_launch_zero(void* p, uint64_t bytes, hipStream_t st); // bytes: a multiple of 16
 uint32_t gs_scan_blocks(uint32_t n);
 void gs_launch_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, unsigned long long* status, uint32_t* ticket, GsControl* ctl,
                     hipStream_t st);

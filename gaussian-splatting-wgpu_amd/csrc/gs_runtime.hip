@@ -460,7 +460,7 @@ static void mark_cb(void* p, int i) { mark((gs_ctx*)p, i); }
 static int32_t record_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* ext_rgba8, bool tight) {
     const GsFrame& f = c->frame;
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(c->ctl_mem, 0, tight ? c->ctl_bytes_tight : c->ctl_bytes, st));
+    gs_launch_zero(c->ctl_mem, tight ? c->ctl_bytes_tight : c->ctl_bytes, st); // (every part is a multiple of 256 bytes)
     c->h_ctl_valid = false;
     if (debug) HIP_TRY(hipMemsetAsync(c->gdata, 0, std::max<size_t>((size_t)c->n * 64, 256), st));
     mark(c, 0);

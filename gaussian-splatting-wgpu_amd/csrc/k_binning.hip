@@ -464,6 +464,18 @@ void gs_launch_rebuild_keys(const uint16_t* tiles, const uint32_t* vals, const u
     const uint32_t blocks = (count + 255u) / 256u;
     hipLaunchKernelGGL(gs_rebuild_keys_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, tiles, vals, counts, count, n, id_mask, keys);
 }
+// The per-frame zeroing of the control block and status words, as a kernel of our own (16-byte stores; `bytes` a multiple of 16):
+// a hipMemsetAsync captured into the frame graph came back as a frame with a garbage control block after other work on the
+// stream between two replays (tools/fuzz_sequence.py); a plain kernel node holds its two arguments by value.
+__global__ __launch_bounds__(256) void gs_zero_kernel(uint4* __restrict__ p, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+void gs_launch_zero(void* p, uint64_t bytes, hipStream_t st) {
+    const uint64_t n16 = bytes / 16;
+    if (!n16) return;
+    const uint64_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(gs_zero_kernel, dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (uint4*)p, n16);
+}
 uint32_t gs_scan_blocks(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 void gs_launch_scan(const uint32_t* counts, uint32_t n, uint32_t* offsets, unsigned long long* status, uint32_t* ticket, GsControl* ctl,
                     hipStream_t st) {
