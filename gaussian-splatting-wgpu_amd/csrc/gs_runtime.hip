@@ -136,6 +136,9 @@ struct gs_ctx {
     uint32_t last_passes = 0;
     bool last_by_index = true;
     uint32_t blend_walkers = 1; // workgroups that walk each tile's list independently in the last frame's blend
+    // what record_frame notes about the frame it records (where the sorted result lives, which pipeline ran): a REPLAY of the
+    // captured frame restores the capture's notes -- a frame recorded in between (gs_render_debug) would otherwise leave its own
+    struct FrameNotes { uint32_t* keysS; uint32_t* valsS; uint32_t last_passes, blend_walkers; bool last_by_index, last_keys16, last_tight; } gnotes{};
     GsControl* h_ctl = nullptr; // pinned copy of the control block's counters, fetched on demand (gs_get_stats)
     bool h_ctl_valid = false;
     GsReport* h_rep = nullptr;    // host-mapped: the frame's last binning kernel writes its report here (gs_device.h); no per-frame copy
@@ -589,9 +592,13 @@ static int32_t enqueue_frame(gs_ctx* c, const GsUniforms& u, bool debug, void* e
                 c->pre_node = nullptr;
             }
             c->gkey_index = c->index_order; c->gkey_tight = tight; c->gkey_ext = ext_rgba8;
+            c->gnotes = {c->keysS, c->valsS, c->last_passes, c->blend_walkers, c->last_by_index, c->last_keys16, c->last_tight};
             c->graph_valid = true;
         } else {
-            c->pre.u = u;
+            c->keysS = c->gnotes.keysS; c->valsS = c->gnotes.valsS; c->last_passes = c->gnotes.last_passes; c->blend_walkers = c->gnotes.blend_walkers;
+            c->last_by_index = c->gnotes.last_by_index; c->last_keys16 = c->gnotes.last_keys16; c->last_tight = c->gnotes.last_tight;
+            // (the launch descriptor too: the frame in between prepared it for ITS projection -- other kernel, grid and outputs)
+            gs_preprocess_prepare(c->pre, c->scene, u, c->frame, c->gdata, c->counts, tight, c->arena, c->rowptr, c->ctl, c->tight_nb);
             hipKernelNodeParams kp{};
             kp.func = const_cast<void*>(c->pre.func);
             kp.gridDim = dim3(c->pre.blocks); kp.blockDim = dim3(256); kp.sharedMemBytes = 0;

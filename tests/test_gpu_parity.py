@@ -701,6 +701,17 @@ def test_frame_graph_replays_the_same_frames():
     np.testing.assert_array_equal(g.read_rgba8(), direct.read_rgba8())
     assert g.stats()["tight_binning"] == 0
     g.set_option(_abi.GS_OPT_TILE_CULL, 1)
+    # a debug frame (reference binning: another projection kernel, grid and outputs) between two replays of one capture: the
+    # replay restores its own launch descriptor and notes (it used to patch the debug frame's into the captured node)
+    g.render_uniforms(us[0]); g.wait()
+    before = g.stats()["graph_frames"]
+    g.render_uniforms(us[1]); g.render_uniforms(us[3], debug=True); g.wait()
+    direct.set_option(_abi.GS_OPT_TILE_CULL, 1)
+    direct.render_uniforms(us[3], debug=True); direct.wait()
+    np.testing.assert_array_equal(g.read_rgba8(), direct.read_rgba8())
+    g.render_uniforms(us[4]); g.wait()
+    np.testing.assert_array_equal(g.read_rgba8(), want[4])
+    assert g.stats()["graph_frames"] == before + 2 and g.stats()["tight_binning"] == 1
     # frames back to back without a wait, three in flight (the shadows of the ring replay their own captures)
     g.set_option(_abi.GS_OPT_FRAMES_IN_FLIGHT, 3)
     before = g.stats()["graph_frames"]

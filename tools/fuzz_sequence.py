@@ -49,7 +49,9 @@ for q in range(seed0, seed0 + seqs):
                 us = []
                 for _ in range(k):
                     u = synth.orbit_camera(int(rng.integers(0, 64)), W, H).uniforms(W, H).copy(); u[39] = np.float32(mod); us.append(u)
-                for u in us: r.render_uniforms(u)
+                dbg = rng.random() < 0.15  # gs_render_debug (reference binning, index order, every tap) as the LAST frame of the burst
+                for u in us[:-1] if dbg else us: r.render_uniforms(u)
+                if dbg: r.render_uniforms(us[-1], debug=True)
                 try:
                     r.wait()
                 except _abi.GsError as e:
@@ -58,7 +60,8 @@ for q in range(seed0, seed0 + seqs):
                 log.append("burst %d" % k)
                 ref = o.render(s, us[-1], W, H, ts)
                 gc.check_image(r, ref, True)
-                if rng.random() < 0.3:
+                if dbg: gc.check_stages(r, ref, exact_image=True)
+                if rng.random() < 0.3 and not dbg:
                     st = r.stats(); assert st["num_gaussians"] == n
                     if st["tight_binning"]: gc.check_product_lists(r, ref, o, W, H, ts)
         r.destroy()
