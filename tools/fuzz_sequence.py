@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: random SEQUENCES of calls on one context -- new scenes of other sizes, option changes (binning, emission order, frames in
-flight, frame graph, projection chunks, workgroup-per-tile blend), bursts of frames without a wait, reads in between -- the last frame
+flight, frame graph, projection chunks, workgroup-per-tile blend), bursts of frames without a wait (a debug frame among them), frames presented through
+gs_render_host with tickets waited for in any order (every sink checked), reads in between -- the last frame
 of every burst against the oracle (EXACT, bit for bit).  Hunts life-cycle bugs (stale captures, ring members with old arrays,
 capacities).  Usage: tools/fuzz_sequence.py [sequences=30] [seed0=0]"""
 import ctypes, os, sys, time
@@ -43,15 +44,44 @@ for q in range(seed0, seed0 + seqs):
                 r.wait()
                 r.set_option(key, val)
                 log.append("opt %d=%d" % (key, val))
+            elif c < 0.60:
+                # pipelined presentation: k frames through gs_render_host into sinks of their own (plain and debug frames of other
+                # cameras enqueued in between), tickets waited for in random order, EVERY sink against the oracle
+                k = int(rng.integers(1, 6))
+                us = [synth.orbit_camera(int(rng.integers(0, 64)), W, H).uniforms(W, H).copy() for _ in range(k)]
+                others = [synth.orbit_camera(int(rng.integers(0, 64)), W, H).uniforms(W, H).copy() for _ in range(k)]
+                for u in us + others:  # capacities first (a ticket's frame is not re-rendered): every member of the ring sees every camera
+                    for _ in range(4): r.render_uniforms(u)
+                    r.wait()
+                nbytes = W * H * 4
+                sinks, tickets = [], []
+                for j, u in enumerate(us):
+                    pp = ctypes.c_void_p(); _abi.check(L.gs_host_alloc(nbytes, ctypes.byref(pp))); sinks.append(pp)
+                    t = ctypes.c_uint64()
+                    uu = np.ascontiguousarray(u, dtype=np.float32)
+                    _abi.check(L.gs_render_host(r._ctx, uu.ctypes.data, pp, nbytes, ctypes.byref(t)))
+                    tickets.append(t.value)
+                    x = rng.random()
+                    if x < 0.25: r.render_uniforms(others[j])
+                    elif x < 0.35: r.render_uniforms(others[j], debug=True)
+                log.append("host %d" % k)
+                for j in rng.permutation(k):
+                    _abi.check(L.gs_wait_ticket(r._ctx, tickets[int(j)]))
+                    got = np.ctypeslib.as_array(ctypes.cast(sinks[int(j)], ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)).reshape(H, W, 4).copy()
+                    ref = o.render(s, us[int(j)], W, H, ts)
+                    np.testing.assert_array_equal(got, ref["rgba8"])
+                r.wait()
+                for pp in sinks: L.gs_host_free(pp)
             else:
                 k = int(rng.integers(1, 5))
                 mod = float(rng.choice([0.5, 1.0, 1.0, 2.5]))
                 us = []
                 for _ in range(k):
                     u = synth.orbit_camera(int(rng.integers(0, 64)), W, H).uniforms(W, H).copy(); u[39] = np.float32(mod); us.append(u)
-                dbg = rng.random() < 0.15  # gs_render_debug (reference binning, index order, every tap) as the LAST frame of the burst
-                for u in us[:-1] if dbg else us: r.render_uniforms(u)
-                if dbg: r.render_uniforms(us[-1], debug=True)
+                # gs_render_debug (reference binning, index order, every tap) as one frame of the burst, anywhere in it
+                dbg_at = int(rng.integers(0, k)) if rng.random() < 0.2 else -1
+                for j, u in enumerate(us): r.render_uniforms(u, debug=(j == dbg_at))
+                dbg = dbg_at == k - 1
                 try:
                     r.wait()
                 except _abi.GsError as e:
