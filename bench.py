@@ -286,9 +286,12 @@ def main():
                          "their launches directly whatever this says).  Default 0: measured no faster on this stack (config A 14.1 k "
                          "vs 14.6 k frames/s: hipGraphLaunch of 16 nodes costs the host what 16 launches do)")
     ap.add_argument("--force-multi", action="store_true", help="rehearsal: run the N > 1 code path with a world of one rank")
-    ap.add_argument("--frame-groups", type=int, default=1,
-                    help="N>1, opt-in: G groups of N/G ranks render alternate frames, every frame being N/G column slabs gathered to "
-                         "rank 0 (multigpu.FrameGroupSlabs).  Default 1 = the N column slabs of SURVEY 8e")
+    ap.add_argument("--frame-groups", type=int, default=0,
+                    help="N>1: G groups of N/G ranks render alternate frames, every frame being N/G column slabs gathered to "
+                         "rank 0 (multigpu.FrameGroupSlabs).  1 = every frame is N column slabs (SURVEY 8e as written).  0 (default) = "
+                         "automatic: N/2 groups of two ranks from 4 GPUs on, else 1 -- a rank's frame has a fixed cost (the O(N) cull, "
+                         "launches too small to fill the chip), so two wide slabs per frame use 8 GPUs better than eight narrow ones "
+                         "(one-GPU projection at 1080p: 6.8x against 3.9x, profiles/r03_slab_per_rank.txt)")
     ap.add_argument("--even-slabs", action="store_true",
                     help="N>1: equal tile-column slabs instead of slabs balanced by the instance counts of a calibration pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")
@@ -385,6 +388,8 @@ def main():
 
     uniforms = [synth.orbit_camera(k, W, H).uniforms(W, H) for k in range(64)]
     owner = xch = pipe = None
+    if args.frame_groups == 0:
+        args.frame_groups = world // 2 if (multi and world >= 4 and world % 2 == 0) else 1
     if args.frame_groups < 1 or world % args.frame_groups:
         raise SystemExit("--frame-groups must divide the number of ranks")
     nslabs = world // args.frame_groups  # slabs per frame

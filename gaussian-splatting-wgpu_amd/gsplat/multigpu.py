@@ -251,9 +251,10 @@ class PipelinedSlabs:
 class FrameGroupSlabs:
     """G groups of S = world / G ranks render ALTERNATE frames; every frame is still S tile-column slabs gathered to rank 0 and
     assembled there.  A rank's frame costs a fixed part (the O(N) cull and scan, launches too small to fill the chip) plus a part
-    proportional to its slab, so fewer, wider slabs per frame use the GPUs better: at 1080p eight slabs project to 4.6x one GPU,
-    two groups of four slabs to 6.0x, four groups of two to 7.3x (profiles/r02_slab_per_rank.txt) -- for a frame latency G
-    times longer.  Opt-in (bench.py --frame-groups G): its sub-communicators have only been rehearsed over gloo on one GPU.
+    proportional to its slab, so fewer, wider slabs per frame use the GPUs better: at 1080p eight slabs project to 3.9x one GPU,
+    two groups of four slabs to 5.3x, four groups of two to 6.8x (profiles/r03_slab_per_rank.txt) -- for a frame latency G
+    times longer.  bench.py's default from 4 ranks on (--frame-groups 0: world / 2 groups of two ranks); rehearsed over gloo with
+    four processes on one GPU and over RCCL with a world of one rank, never run on multi-GPU hardware.
 
     Frame k belongs to group k % G.  Rank r is slab r % S of group r // S.  Communicator h holds the ranks of group h and, for
     h > 0, rank 0, which receives every frame; rank 0 issues the gathers of ALL frames in frame order on its communication
