@@ -263,13 +263,14 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
 // skipped altogether; at tile 32 the bit is per 16x16 quadrant and the cull still runs on what the bit lets through.
 #ifdef GS_PROFILING
 // PROFILING BUILD ONLY: footprint of the evaluations -- [0] evaluations, [1] lanes with alpha >= 1/255, [2] 4x4 pixel quads (of the
-// block's four) holding such a lane, [3] evaluations with none; 256 copies 128 bytes apart
+// block's four) holding such a lane, [3] evaluations with none, [4] live lanes (pixel not final), [5] kept lanes (both tests), [6] evaluations
+// whose alpha >= 1/255 lanes are all final, [7] evaluations with <= 16 live lanes (out: 8 words); 256 copies 128 bytes apart
 __device__ unsigned long long gs_blend_foot[256][16];
 extern "C" __attribute__((visibility("default"))) int gs_prof_blend_footprint(unsigned long long* out4, int reset) {
     static unsigned long long h[256][16];
     if (out4) {
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_blend_foot), sizeof(h)) != hipSuccess) return -1;
-        for (int k = 0; k < 4; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
+        for (int k = 0; k < 8; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
     }
     if (reset) { for (auto& r : h) for (auto& v : r) v = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(gs_blend_foot), h, sizeof(h)) != hipSuccess) return -1; }
     return 0;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     uint32_t staged = 0, evaluated = 0;
 #ifdef GS_PROFILING
-    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0;
+    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0, fp_live = 0, fp_kept = 0, fp_dead = 0, fp_q1 = 0;
 #endif
 
     // the three pieces of a record a lane fetches (uv | conic | colour, opacity), as native vectors: each is ONE register tuple
@@ -351,7 +352,6 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     gs_u32x3 r1 = {0u, 0u, 0u};
     gs_u32x4 r2 = {0u, 0u, 0u, 0u};
     // this walker's bit of the mask: its 8x8 block at tile 16, the 16x16 quadrant holding it at tile 32
-    constexpr bool QCULL = !MASKED || TS == 32;
     const uint32_t mybit = GS_ID_BITS + (TS == 32 ? ((q / BPR) / 2u) * 2u + ((q % BPR) / 2u) : q);
     // The ID STREAM.  A walker's bit is set in about three of eight entries of its tile's list (tile 16).  Round 2 parked the
     // survivors of every 64 list entries -- 24 on average -- so the per-batch work (the row tables: 4 instructions and an LDS
@@ -427,16 +427,26 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         const float gxp = __uint_as_float(r0.x) * Wf, gyp = __uint_as_float(r0.y) * Hf; // compute_tiles.wgsl:52
         const float cx = __uint_as_float(r1.x), cy = __uint_as_float(r1.y), cz = __uint_as_float(r1.z);
         const float op = __uint_as_float(r2.w);
+        // THE LIVE BOX.  Whatever decided that an entry can touch this block (the binning's mask bit at tile 16, nothing in a
+        // reference-binning frame) decided it for the block's 64 pixels -- but most of them are FINAL long before the block is:
+        // at an average evaluation 8 of the 64 pixels were still live, and a third of the evaluations touched final pixels only
+        // (tools/blend_footprint.py, config B: the block lives as long as its last pixel).  A final pixel ignores every later
+        // entry, so an entry is parked only if its alpha >= 1/255 ellipse reaches the BOUNDING BOX OF THE PIXELS THAT
+        // ARE STILL LIVE (conservative closed form, block_qmin): no output bit changes, 27 % fewer evaluations at config B
+        // (blend 495 -> 418 us).  The box is taken by the whole wave, outside the branch of the lanes that hold an entry.
+        const unsigned long long lv = __ballot(!done);
+        uint32_t lcm = (uint32_t)lv | (uint32_t)(lv >> 32);
+        lcm |= lcm >> 16; lcm |= lcm >> 8; lcm &= 0xFFu; // columns of the block that hold a live pixel
+        const float lc0 = (float)__builtin_ctz(lcm | 0x100u), lc1 = (float)(31 - __builtin_clz(lcm | 1u));
+        const float lr0 = (float)(__builtin_ctzll(lv | (1ull << 63)) >> 3), lr1 = (float)((63 - __builtin_clzll(lv | 1ull)) >> 3);
         if (lane < cnt) {
             const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
             const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
-            if (QCULL) {
-                const float dxhi = gxp - bx0f, dyhi = gyp - by0f;
+            {   // (at tile 16 the binning's mask bit has already said "this block": the box is what is left to test)
+                const float dxh = gxp - bx0f, dyh = gyp - by0f;
                 float mag;
-                const float qm = block_qmin(cx, cy, cz, dxhi - 7.0f, dxhi, dyhi - 7.0f, dyhi, mag);
-                rel = !pd || !(qm > lim + 1.0e-5f * mag);
-            } else {
-                rel = true; // the binning already decided it for exactly these 64 pixels
+                const float qm = block_qmin(cx, cy, cz, dxh - lc1, dxh - lc0, dyh - lr1, dyh - lr0, mag);
+                rel = lv != 0ull && (!pd || !(qm > lim + 1.0e-5f * mag)); // (no live pixel: a block outside the canvas)
             }
 #ifdef GS_PROFILING
             if (dbg & 1u) rel = false; // staging cost without the pixel loop
@@ -520,6 +530,13 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                         fp_lanes += (uint32_t)__popcll(km);
                         fp_quads += (uint32_t)((km & q0) != 0) + (uint32_t)((km & (q0 << 4)) != 0) + (uint32_t)((km & (q0 << 32)) != 0) + (uint32_t)((km & (q0 << 36)) != 0);
                         fp_none += (uint32_t)(km == 0);
+                        // lanes whose pixel is still live (an entry can still pass its transmittance test) and what the entry does to them
+                        const unsigned long long lv = __ballot(__builtin_fmaf(-T, c255, T) >= 0.0001f);
+                        const unsigned long long kp = __ballot(ea >= k1 && __builtin_fmaf(T * ea, -0.99f, T) >= 0.0001f);
+                        fp_live += (uint32_t)__popcll(lv);
+                        fp_kept += (uint32_t)__popcll(kp);
+                        fp_dead += (uint32_t)((km & lv) == 0);
+                        fp_q1 += (uint32_t)(__popcll(lv) <= 16);
                     }
 #endif
                     if (CHECKED) {
@@ -598,6 +615,8 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         unsigned long long* fp = gs_blend_foot[b & 255u];
         atomicAdd(&fp[0], (unsigned long long)evaluated); atomicAdd(&fp[1], (unsigned long long)fp_lanes);
         atomicAdd(&fp[2], (unsigned long long)fp_quads); atomicAdd(&fp[3], (unsigned long long)fp_none);
+        atomicAdd(&fp[4], (unsigned long long)fp_live); atomicAdd(&fp[5], (unsigned long long)fp_kept);
+        atomicAdd(&fp[6], (unsigned long long)fp_dead); atomicAdd(&fp[7], (unsigned long long)fp_q1);
     }
     if (prof && lane == 0) {
         prof[b * 4u + 0u] = t_start;
