@@ -264,13 +264,13 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
 #ifdef GS_PROFILING
 // PROFILING BUILD ONLY: footprint of the evaluations -- [0] evaluations, [1] lanes with alpha >= 1/255, [2] 4x4 pixel quads (of the
 // block's four) holding such a lane, [3] evaluations with none, [4] live lanes (pixel not final), [5] kept lanes (both tests), [6] evaluations
-// whose alpha >= 1/255 lanes are all final, [7] evaluations with <= 16 live lanes (out: 8 words); 256 copies 128 bytes apart
+// whose alpha >= 1/255 lanes are all final, [7] evaluations with <= 16 live lanes, [8] entries parked while <= 16 pixels are live, [9] blocks of the tile their masks name (out: 10 words); 256 copies 128 bytes apart
 __device__ unsigned long long gs_blend_foot[256][16];
 extern "C" __attribute__((visibility("default"))) int gs_prof_blend_footprint(unsigned long long* out4, int reset) {
     static unsigned long long h[256][16];
     if (out4) {
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_blend_foot), sizeof(h)) != hipSuccess) return -1;
-        for (int k = 0; k < 8; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
+        for (int k = 0; k < 10; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
     }
     if (reset) { for (auto& r : h) for (auto& v : r) v = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(gs_blend_foot), h, sizeof(h)) != hipSuccess) return -1; }
     return 0;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     uint32_t staged = 0, evaluated = 0;
 #ifdef GS_PROFILING
-    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0, fp_live = 0, fp_kept = 0, fp_dead = 0, fp_q1 = 0;
+    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0, fp_live = 0, fp_kept = 0, fp_dead = 0, fp_q1 = 0, fp_tailn = 0, fp_tailbits = 0;
 #endif
 
     // the three pieces of a record a lane fetches (uv | conic | colour, opacity), as native vectors: each is ONE register tuple
@@ -456,6 +456,14 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         // only surviving entries are parked for the broadcast, DENSELY (slot = rank among the survivors, list order kept): the
         // evaluation loop then walks slots 0, 1, 2 ... with immediate LDS offsets, four per trip, instead of deriving an address
         // from a bit scan for every entry (one VALU move per evaluation in a loop that runs at the VALU issue rate)
+#ifdef GS_PROFILING
+        if ((dbg & 32u) && MASKED && __popcll(lv) <= 16) { // parked entries while <= 16 pixels are live: how many of the tile's 4 blocks does the entry's mask name?
+            const unsigned long long rm = __ballot(rel);
+            const uint32_t bits = __popc((vnext >> GS_ID_BITS) & 15u);
+            fp_tailn += (uint32_t)__popcll(rm);
+            fp_tailbits += (uint32_t)__popcll(__ballot(rel && bits >= 1u)) + (uint32_t)__popcll(__ballot(rel && bits >= 2u)) + (uint32_t)__popcll(__ballot(rel && bits >= 3u)) + (uint32_t)__popcll(__ballot(rel && bits >= 4u));
+        }
+#endif
         const unsigned long long m = __ballot(rel);
         if (rel) {
             const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -617,6 +625,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         atomicAdd(&fp[2], (unsigned long long)fp_quads); atomicAdd(&fp[3], (unsigned long long)fp_none);
         atomicAdd(&fp[4], (unsigned long long)fp_live); atomicAdd(&fp[5], (unsigned long long)fp_kept);
         atomicAdd(&fp[6], (unsigned long long)fp_dead); atomicAdd(&fp[7], (unsigned long long)fp_q1);
+        atomicAdd(&fp[8], (unsigned long long)fp_tailn); atomicAdd(&fp[9], (unsigned long long)fp_tailbits);
     }
     if (prof && lane == 0) {
         prof[b * 4u + 0u] = t_start;
