@@ -264,13 +264,13 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
 #ifdef GS_PROFILING
 // PROFILING BUILD ONLY: footprint of the evaluations -- [0] evaluations, [1] lanes with alpha >= 1/255, [2] 4x4 pixel quads (of the
 // block's four) holding such a lane, [3] evaluations with none, [4] live lanes (pixel not final), [5] kept lanes (both tests), [6] evaluations
-// whose alpha >= 1/255 lanes are all final, [7] evaluations with <= 16 live lanes, [8] entries parked while <= 16 pixels are live, [9] blocks of the tile their masks name (out: 10 words); 256 copies 128 bytes apart
+// whose alpha >= 1/255 lanes are all final, [7] evaluations with <= 16 live lanes, [8] entries parked while <= 16 pixels are live, [9] blocks of the tile their masks name, [10] evaluations that keep no lane (out: 11 words); 256 copies 128 bytes apart
 __device__ unsigned long long gs_blend_foot[256][16];
 extern "C" __attribute__((visibility("default"))) int gs_prof_blend_footprint(unsigned long long* out4, int reset) {
     static unsigned long long h[256][16];
     if (out4) {
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_blend_foot), sizeof(h)) != hipSuccess) return -1;
-        for (int k = 0; k < 10; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
+        for (int k = 0; k < 11; ++k) { out4[k] = 0; for (int c = 0; c < 256; ++c) out4[k] += h[c][k]; }
     }
     if (reset) { for (auto& r : h) for (auto& v : r) v = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(gs_blend_foot), h, sizeof(h)) != hipSuccess) return -1; }
     return 0;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
     uint32_t staged = 0, evaluated = 0;
 #ifdef GS_PROFILING
-    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0, fp_live = 0, fp_kept = 0, fp_dead = 0, fp_q1 = 0, fp_tailn = 0, fp_tailbits = 0;
+    uint32_t fp_lanes = 0, fp_quads = 0, fp_none = 0, fp_live = 0, fp_kept = 0, fp_dead = 0, fp_q1 = 0, fp_tailn = 0, fp_tailbits = 0, fp_nokeep = 0;
 #endif
 
     // the three pieces of a record a lane fetches (uv | conic | colour, opacity), as native vectors: each is ONE register tuple
@@ -439,6 +439,13 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         lcm |= lcm >> 16; lcm |= lcm >> 8; lcm &= 0xFFu; // columns of the block that hold a live pixel
         const float lc0 = (float)__builtin_ctz(lcm | 0x100u), lc1 = (float)(31 - __builtin_clz(lcm | 1u));
         const float lr0 = (float)(__builtin_ctzll(lv | (1ull << 63)) >> 3), lr1 = (float)((63 - __builtin_clzll(lv | 1ull)) >> 3);
+        // ... AND THE TRANSMITTANCE THAT IS LEFT.  A live pixel whose T is just above the final threshold (1.0039e-4) accepts only
+        // entries with alpha <= 1 - 1e-4 / T -- a few per cent -- and stays live, keeping its block alive, until one comes: 84 % of
+        // the evaluations that the live box leaves keep NO lane (tools/blend_footprint.py).  With Tmax = the largest T among the live
+        // pixels and a lower bound of the entry's alpha over the live box (the quadratic's maximum is at a corner), an entry whose
+        // Tmax (1 - alpha_lo) is below 1e-4 with margins fails `T (1 - alpha) >= 1e-4` on every live pixel: not parked, no bit changes
+        // (config B: blend 412 -> 278 us).
+        const float Tmax = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(done ? 0u : __float_as_uint(T)), 63)); // (T >= 0; a NaN is the largest)
         if (lane < cnt) {
             const float lim = __builtin_amdgcn_logf(op * 255.0f) * 0.693147182464599609375f + 0.01f; // alpha >= c255 <=> q <= ln(255*op)
             const bool pd = (cx > 0.0f) && (cz > 0.0f) && (cx * cz - cy * cy > 0.0f);
@@ -447,6 +454,19 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 float mag;
                 const float qm = block_qmin(cx, cy, cz, dxh - lc1, dxh - lc0, dyh - lr1, dyh - lr0, mag);
                 rel = lv != 0ull && (!pd || !(qm > lim + 1.0e-5f * mag)); // (no live pixel: a block outside the canvas)
+#ifndef GS_NO_TMAX // (A/B: tools/build_variant.py notmax -DGS_NO_TMAX)
+                if (rel && pd) {
+                    const float x0 = dxh - lc1, x1 = dxh - lc0, y0 = dyh - lr1, y1 = dyh - lr0;
+                    const float ax0 = (0.5f * cx) * x0 * x0, ax1 = (0.5f * cx) * x1 * x1, by0 = (0.5f * cz) * y0 * y0, by1 = (0.5f * cz) * y1 * y1;
+                    const float c00 = cy * x0 * y0, c01 = cy * x0 * y1, c10 = cy * x1 * y0, c11 = cy * x1 * y1;
+                    const float qmax = __builtin_fmaxf(__builtin_fmaxf(ax0 + by0 + c00, ax0 + by1 + c01), __builtin_fmaxf(ax1 + by0 + c10, ax1 + by1 + c11));
+                    const float qmag = __builtin_fmaxf(ax0, ax1) + __builtin_fmaxf(by0, by1) +
+                                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c00), __builtin_fabsf(c01)), __builtin_fmaxf(__builtin_fabsf(c10), __builtin_fabsf(c11)));
+                    // alpha >= min(0.99, op exp(-qmax)) on every live pixel; 1 % off for the roundings of q, exp and the loop's own alpha
+                    const float alo = 0.99f * __builtin_fminf(0.99f, op * __builtin_amdgcn_exp2f(-1.44269502162933349609375f * (qmax + 1.0e-5f * qmag)));
+                    if (Tmax * (1.0f - alo) < 0.0000999f) rel = false; // (NaN anywhere: the comparison is false, the entry stays)
+                }
+#endif
             }
 #ifdef GS_PROFILING
             if (dbg & 1u) rel = false; // staging cost without the pixel loop
@@ -545,6 +565,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                         fp_kept += (uint32_t)__popcll(kp);
                         fp_dead += (uint32_t)((km & lv) == 0);
                         fp_q1 += (uint32_t)(__popcll(lv) <= 16);
+                        fp_nokeep += (uint32_t)(kp == 0ull);
                     }
 #endif
                     if (CHECKED) {
@@ -625,7 +646,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
         atomicAdd(&fp[2], (unsigned long long)fp_quads); atomicAdd(&fp[3], (unsigned long long)fp_none);
         atomicAdd(&fp[4], (unsigned long long)fp_live); atomicAdd(&fp[5], (unsigned long long)fp_kept);
         atomicAdd(&fp[6], (unsigned long long)fp_dead); atomicAdd(&fp[7], (unsigned long long)fp_q1);
-        atomicAdd(&fp[8], (unsigned long long)fp_tailn); atomicAdd(&fp[9], (unsigned long long)fp_tailbits);
+        atomicAdd(&fp[8], (unsigned long long)fp_tailn); atomicAdd(&fp[9], (unsigned long long)fp_tailbits); atomicAdd(&fp[10], (unsigned long long)fp_nokeep);
     }
     if (prof && lane == 0) {
         prof[b * 4u + 0u] = t_start;
