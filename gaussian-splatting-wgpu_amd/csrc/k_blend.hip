@@ -467,6 +467,24 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                     if (Tmax * (1.0f - alo) < 0.0000999f) rel = false; // (NaN anywhere: the comparison is false, the entry stays)
                 }
 #endif
+#ifdef GS_BLEND_PIXTEST
+                // few live pixels: the same two tests per PIXEL instead of per box (alpha within its rounding bounds at the pixel, against
+                // 1/255 and against what the pixel's own T still accepts)
+                if (rel && pd && (uint32_t)__popcll(lv) <= GS_BLEND_PIXTEST) {
+                    bool any = false;
+                    for (unsigned long long mm = lv; mm; mm &= mm - 1ull) {
+                        const int pl = __builtin_ctzll(mm);
+                        const float Tp = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(T), pl));
+                        const float dx = dxh - (float)(pl & 7), dy = dyh - (float)(pl >> 3);
+                        const float a = (0.5f * cx) * dx * dx, b = (0.5f * cz) * dy * dy, c = cy * dx * dy;
+                        const float q = a + b + c, mg = 1.0e-5f * (a + b + __builtin_fabsf(c));
+                        const float ahi = 1.01f * (op * __builtin_amdgcn_exp2f(-1.44269502162933349609375f * (q - mg)));
+                        const float alo = 0.99f * __builtin_fminf(0.99f, op * __builtin_amdgcn_exp2f(-1.44269502162933349609375f * (q + mg)));
+                        any = any || !(ahi < c255 || Tp * (1.0f - alo) < 0.0000999f); // (NaN: kept)
+                    }
+                    rel = any;
+                }
+#endif
             }
 #ifdef GS_PROFILING
             if (dbg & 1u) rel = false; // staging cost without the pixel loop
