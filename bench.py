@@ -291,7 +291,7 @@ def main():
                          "rank 0 (multigpu.FrameGroupSlabs).  1 = every frame is N column slabs (SURVEY 8e as written).  0 (default) = "
                          "automatic: N/2 groups of two ranks from 4 GPUs on, else 1 -- a rank's frame has a fixed cost (the O(N) cull, "
                          "launches too small to fill the chip), so two wide slabs per frame use 8 GPUs better than eight narrow ones "
-                         "(one-GPU projection at 1080p: 6.8x against 3.9x, profiles/r03_slab_per_rank.txt)")
+                         "(one-GPU projection at 1080p: 6.7x against 3.6x, profiles/r03_slab_per_rank.txt)")
     ap.add_argument("--even-slabs", action="store_true",
                     help="N>1: equal tile-column slabs instead of slabs balanced by the instance counts of a calibration pass")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run checks (N>1: assembled frame vs a whole-canvas render; N=1: self_check)")

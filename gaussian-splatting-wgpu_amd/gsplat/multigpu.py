@@ -251,8 +251,8 @@ class PipelinedSlabs:
 class FrameGroupSlabs:
     """G groups of S = world / G ranks render ALTERNATE frames; every frame is still S tile-column slabs gathered to rank 0 and
     assembled there.  A rank's frame costs a fixed part (the O(N) cull and scan, launches too small to fill the chip) plus a part
-    proportional to its slab, so fewer, wider slabs per frame use the GPUs better: at 1080p eight slabs project to 3.9x one GPU,
-    two groups of four slabs to 5.3x, four groups of two to 6.8x (profiles/r03_slab_per_rank.txt) -- for a frame latency G
+    proportional to its slab, so fewer, wider slabs per frame use the GPUs better: at 1080p eight slabs project to 3.6x one GPU,
+    two groups of four slabs to 4.9x, four groups of two to 6.7x (profiles/r03_slab_per_rank.txt) -- for a frame latency G
     times longer.  bench.py's default from 4 ranks on (--frame-groups 0: world / 2 groups of two ranks); rehearsed over gloo with
     four processes on one GPU and over RCCL with a world of one rank, never run on multi-GPU hardware.
 
