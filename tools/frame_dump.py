@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""scratch: product frame (f32 tap) of a scaled config-B scene with the library in $GSPLAT_LIB -> npy.  args: n W H out [ablation] [fused]"""
+"""GPU box: product frames (f32 tap) of a scaled config-B scene with the library in $GSPLAT_LIB -> npy.  args: n W H out [ablation] [fused]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-wgpu_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gsplat
