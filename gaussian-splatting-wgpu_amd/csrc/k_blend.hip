@@ -453,9 +453,10 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
                 const float dxh = gxp - bx0f, dyh = gyp - by0f;
                 float mag;
                 const float qm = block_qmin(cx, cy, cz, dxh - lc1, dxh - lc0, dyh - lr1, dyh - lr0, mag);
-                rel = lv != 0ull && (!pd || !(qm > lim + 1.0e-5f * mag)); // (no live pixel: a block outside the canvas)
+                const bool nocull = (dbg & 4u) != 0u; // GS_OPT_BLEND_ABLATION bit 2: both culls off (tests: they must not change a bit)
+                rel = lv != 0ull && (nocull || !pd || !(qm > lim + 1.0e-5f * mag)); // (no live pixel: a block outside the canvas)
 #ifndef GS_NO_TMAX // (A/B: tools/build_variant.py notmax -DGS_NO_TMAX)
-                if (rel && pd) {
+                if (rel && pd && !nocull) {
                     const float x0 = dxh - lc1, x1 = dxh - lc0, y0 = dyh - lr1, y1 = dyh - lr0;
                     const float ax0 = (0.5f * cx) * x0 * x0, ax1 = (0.5f * cx) * x1 * x1, by0 = (0.5f * cz) * y0 * y0, by1 = (0.5f * cz) * y1 * y1;
                     const float c00 = cy * x0 * y0, c01 = cy * x0 * y1, c10 = cy * x1 * y0, c11 = cy * x1 * y1;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64) void gs_blend_quad_kernel(const uint4* __restri
 #ifdef GS_BLEND_PIXTEST
                 // few live pixels: the same two tests per PIXEL instead of per box (alpha within its rounding bounds at the pixel, against
                 // 1/255 and against what the pixel's own T still accepts)
-                if (rel && pd && (uint32_t)__popcll(lv) <= GS_BLEND_PIXTEST) {
+                if (rel && pd && !nocull && (uint32_t)__popcll(lv) <= GS_BLEND_PIXTEST) {
                     bool any = false;
                     for (unsigned long long mm = lv; mm; mm &= mm - 1ull) {
                         const int pl = __builtin_ctzll(mm);

@@ -206,7 +206,8 @@ int32_t gs_device_ptr(gs_ctx* ctx, int32_t which, void** d_ptr);
 int32_t gs_get_stats(gs_ctx* ctx, gs_stats* out);
 /* Tuning / profiling knobs. */
 #define GS_OPT_BLEND_ABLATION 1  /* bit 3 (8): the workgroup-per-tile blend kernel at tiles 16 and 32 (identical results; default = one
-                                    wave per 8x8 pixel block); bits 8-15: tile-column strip width of the default kernel's XCD mapping
+                                    wave per 8x8 pixel block); bit 2 (4): the default kernel without its two parking culls (live box,
+                                    transmittance bound: identical results, slower -- the test that they change no bit); bits 8-15: tile-column strip width of the default kernel's XCD mapping
                                     (0 = automatic).  The remaining bits act only in the PROFILING build (csrc/build.py --profiling,
                                     libgsplat_hip_prof.so; the product library ignores them): bits 0/1 break the image (1 skip the
                                     pixel loop, 2 gather from a cache-resident window), bit 5 counts the evaluations' footprint

@@ -670,6 +670,37 @@ def test_render_host_tickets(oracle):
         L.gs_host_free(p)
 
 
+def test_blend_culls_change_no_bit():
+    """The blend parks an entry only if it can still change a LIVE pixel of the block: its alpha >= 1/255 ellipse must reach the
+    bounding box of the pixels that are not final yet, and Tmax (1 - alpha_lo) over that box must reach 1e-4.  Both tests are
+    conservative, a final pixel ignores every entry and a live one skips what fails `T (1 - alpha) >= 1e-4` anyway: the frame with the
+    culls (default) and without them (GS_OPT_BLEND_ABLATION 4) is the same frame, bit for bit, in BOTH blend modes -- on a scene deep
+    enough that most blocks saturate (hundreds of splats per pixel), with opaque and faint splats, at tiles 16 and 32."""
+    from gsplat import _abi
+    n, W, H = 400000, 256, 144
+    s = scene(n).copy()
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, n, n // 5)
+    s[idx, 12] = rng.choice([6.0, 2.0, -4.0, -5.4], idx.size).astype(np.float32)  # opacity logits: opaque ... just above 1/255
+    for ts in (16, 32):
+        for flags in (0, _abi.GS_FLAG_EXACT_BLEND):
+            r = _mk(s, W, H, ts, flags=flags)
+            for step in (2, 33):
+                u = _uniforms(W, H, step=step)
+                r.set_option(_abi.GS_OPT_BLEND_ABLATION, 0)
+                r.render_uniforms(u); r.wait()
+                ev_cull = r.stats()["num_evaluated"]
+                img = r.read_rgba8()
+                f32 = r.read_buffer(_abi.GS_BUF_RGB_F32, np.float32).copy()
+                r.set_option(_abi.GS_OPT_BLEND_ABLATION, 4)
+                r.render_uniforms(u); r.wait()
+                ev_all = r.stats()["num_evaluated"]
+                np.testing.assert_array_equal(r.read_buffer(_abi.GS_BUF_RGB_F32, np.float32).view(np.uint32), f32.view(np.uint32))
+                np.testing.assert_array_equal(r.read_rgba8(), img)
+                assert ev_cull < ev_all, (ts, flags, ev_cull, ev_all)  # the culls do remove work (10 % here; 75 % at config B, where most blocks saturate)
+            r.destroy()
+
+
 def test_frame_graph_replays_the_same_frames():
     """GS_OPT_FRAME_GRAPH: frames replayed from the captured hipGraph (uniforms patched into the projection's node) are the
     frames the directly issued launches give -- moving camera, an option change (re-capture), a capacity regrow on the first
