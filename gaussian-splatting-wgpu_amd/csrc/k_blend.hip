@@ -53,6 +53,19 @@ __device__ __forceinline__ float block_qmin(float cx, float cy, float cz, float 
     return q;
 }
 
+// The transmittance cull of the blend walkers (see gs_blend_quad_kernel, "... and the transmittance that is left"): true if
+// Tmax (1 - alpha_lo) < 1e-4 with margins, alpha_lo a lower bound of the entry's alpha over the box [dxlo,dxhi] x [dylo,dyhi]
+// (offsets centre - pixel; the quadratic's maximum over a rectangle is at a corner).  Positive-definite conics only.
+__device__ __forceinline__ bool blend_tmax_cull(float cx, float cy, float cz, float op, float dxlo, float dxhi, float dylo, float dyhi, float Tmax) {
+    const float ax0 = (0.5f * cx) * dxlo * dxlo, ax1 = (0.5f * cx) * dxhi * dxhi, by0 = (0.5f * cz) * dylo * dylo, by1 = (0.5f * cz) * dyhi * dyhi;
+    const float c00 = cy * dxlo * dylo, c01 = cy * dxlo * dyhi, c10 = cy * dxhi * dylo, c11 = cy * dxhi * dyhi;
+    const float qmax = __builtin_fmaxf(__builtin_fmaxf(ax0 + by0 + c00, ax0 + by1 + c01), __builtin_fmaxf(ax1 + by0 + c10, ax1 + by1 + c11));
+    const float qmag = __builtin_fmaxf(ax0, ax1) + __builtin_fmaxf(by0, by1) +
+                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c00), __builtin_fabsf(c01)), __builtin_fmaxf(__builtin_fabsf(c10), __builtin_fabsf(c11)));
+    const float alo = 0.99f * __builtin_fminf(0.99f, op * __builtin_amdgcn_exp2f(-1.44269502162933349609375f * (qmax + 1.0e-5f * qmag)));
+    return Tmax * (1.0f - alo) < 0.0000999f; // (NaN anywhere: false, the entry stays)
+}
+
 // One workgroup per tile, TS*TS threads, one pixel per thread; wave w owns the 8x8 pixel block
 // (w % (TS/8), w / (TS/8)) of the tile.  The tile's sorted list is consumed in batches of TS*TS
 // entries through a DOUBLE-BUFFERED LDS stage: while a batch is being blended, the next batch's
@@ -156,7 +169,14 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
         }
         const uint32_t cnt = (end - b < (uint32_t)NT) ? end - b : (uint32_t)NT;
         staged += cnt;
-        if (__ballot(!done) != 0ull) { // otherwise this wave's 8x8 block is final (uniform per wave)
+        const unsigned long long lv = __ballot(!done);
+        if (lv != 0ull) { // otherwise this wave's 8x8 block is final (uniform per wave)
+            // the live box and the transmittance left in it (as in gs_blend_quad_kernel: an entry that cannot change a live pixel is skipped)
+            uint32_t lcm = (uint32_t)lv | (uint32_t)(lv >> 32);
+            lcm |= lcm >> 16; lcm |= lcm >> 8; lcm &= 0xFFu;
+            const float lc0 = (float)__builtin_ctz(lcm | 0x100u), lc1 = (float)(31 - __builtin_clz(lcm | 1u));
+            const float lr0 = (float)(__builtin_ctzll(lv) >> 3), lr1 = (float)((63 - __builtin_clzll(lv)) >> 3);
+            const float Tmax = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(done ? 0u : __float_as_uint(T)), 63));
 #pragma unroll 1
             for (int r = 0; r < ROUNDS; ++r) {
                 const uint32_t e0 = (uint32_t)r * 64u;
@@ -171,11 +191,13 @@ __global__ __launch_bounds__(TS* TS) void gs_blend_kernel(const uint4* __restric
                         p1.y *= -iL;
                         p1.z *= -2.0f * iL;
                     }
-                    const float dxhi = p0.x - bx0f, dxlo = dxhi - 7.0f, dyhi = p0.y - by0f, dylo = dyhi - 7.0f;
+                    const float dxh = p0.x - bx0f, dyh = p0.y - by0f;
+                    const float dxlo = dxh - lc1, dxhi = dxh - lc0, dylo = dyh - lr1, dyhi = dyh - lr0; // the LIVE pixels' box
                     const bool pd = (p1.x > 0.0f) && (p1.z > 0.0f) && (p1.x * p1.z - p1.y * p1.y > 0.0f);
                     float mag;
                     const float q = block_qmin(p1.x, p1.y, p1.z, dxlo, dxhi, dylo, dyhi, mag);
                     rel = !pd || !(q > p0.z + 1.0e-5f * mag); // NaNs compare false -> relevant
+                    if (rel && pd && blend_tmax_cull(p1.x, p1.y, p1.z, sP2[buf][e0 + lane].w, dxlo, dxhi, dylo, dyhi, Tmax)) rel = false;
 #ifdef GS_PROFILING
                     if (dbg & 1u) rel = false; // staging + cull cost without the pixel loop
 #endif
